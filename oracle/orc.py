@@ -1,0 +1,357 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (ctypes loader for oracle/liboracle.so + small pure-Python restatements).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product path (cramtools_amd/) never does.
+
+Pure-Python parts restate host-only logic of the reference:
+  parse_policies   QualityScorePreservation.parsePolicies/parseSinglePolicy/readTreatment
+                   (src/main/java/htsjdk/samtools/cram/lossy/QualityScorePreservation.java:139-256)
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+RF_UNMAPPED, RF_NULL_QUALS, RF_NO_BASES, RF_UNKNOWN_BASES, RF_FORCE_QS, RF_SKIP = 1, 2, 4, 8, 16, 32
+
+READ_CATS = {None: 0, "UNPLACED": 1, "HIGHER_MAPPING_SCORE": 2, "LOWER_MAPPING_SCORE": 3, "ALL": 4}
+BASE_CATS = {"MATCH": 1, "MISMATCH": 2, "FLANKING_DELETION": 3, "PILEUP": 4, "LOWER_COVERAGE": 5, "INSERTION": 6}
+TREATMENTS = {"PRESERVE": 0, "BIN": 1, "DROP": 2}
+
+
+class Policy(ctypes.Structure):
+    _fields_ = [
+        ("read_cat", ctypes.c_int32),
+        ("read_param", ctypes.c_int32),
+        ("treatment", ctypes.c_int32),
+        ("n_base_cat", ctypes.c_int32),
+        ("base_cat", ctypes.c_int32 * 8),
+        ("base_param", ctypes.c_int32 * 8),
+    ]
+
+
+def build():
+    """Compile liboracle.so with gcc (idempotent)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("rans4x8.c", "records.c")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+        _LIB.orc_rans_bound.restype = ctypes.c_int32
+        _LIB.orc_rans_compress.restype = ctypes.c_int32
+        _LIB.orc_rans_uncompress.restype = ctypes.c_int32
+        _LIB.orc_rans_raw_size.restype = ctypes.c_int32
+        _LIB.orc_rans_compress_many.restype = ctypes.c_int64
+        _LIB.orc_extract_features.restype = ctypes.c_int64
+        _LIB.orc_merge_quality_features.restype = ctypes.c_int64
+        _LIB.orc_lossy_quals.restype = ctypes.c_int32
+        _LIB.orc_tracks_windows.restype = ctypes.c_int32
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _u8(b):
+    return np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else np.ascontiguousarray(b, np.uint8)
+
+
+# ---------------------------------------------------------------- rANS
+def rans_bound(n):
+    return lib().orc_rans_bound(ctypes.c_int32(n))
+
+
+def rans(data, order):
+    """ExternalCompression.rans(byte[], int) -> bytes; raises on the reference's error conditions."""
+    d = _u8(data)
+    n = d.size
+    cap = rans_bound(n)
+    out = np.empty(max(cap, 1), np.uint8)
+    r = lib().orc_rans_compress(_p(d), ctypes.c_int32(n), ctypes.c_int32(order), _p(out), ctypes.c_int32(cap))
+    if r < 0:
+        raise RuntimeError("oracle rans error %d" % r)
+    return out[:r].tobytes()
+
+
+def unrans(data):
+    d = _u8(data)
+    n = d.size
+    raw = lib().orc_rans_raw_size(_p(d), ctypes.c_int32(n))
+    if raw < 0:
+        raise RuntimeError("oracle unrans error %d" % raw)
+    out = np.empty(max(raw, 1), np.uint8)
+    r = lib().orc_rans_uncompress(_p(d), ctypes.c_int32(n), _p(out), ctypes.c_int32(raw))
+    if r < 0:
+        raise RuntimeError("oracle unrans error %d" % r)
+    return out[:r].tobytes()
+
+
+def rans_many(arena, in_off, in_len, order):
+    """Compress many blocks of one arena; returns (out_arena, out_off, out_len)."""
+    arena = _u8(arena)
+    in_off = np.ascontiguousarray(in_off, np.int64)
+    in_len = np.ascontiguousarray(in_len, np.int32)
+    order = np.ascontiguousarray(order, np.int32)
+    caps = np.array([rans_bound(int(x)) for x in in_len], np.int64)
+    out_off = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.int64)
+    out = np.empty(int(caps.sum()) + 1, np.uint8)
+    out_len = np.empty(in_len.size, np.int32)
+    r = lib().orc_rans_compress_many(_p(arena), _p(in_off), _p(in_len), _p(order), ctypes.c_int32(in_len.size),
+                                     _p(out), _p(out_off), _p(out_len))
+    if r < 0:
+        raise RuntimeError("oracle rans_many error %d" % r)
+    return out, out_off, out_len
+
+
+# ---------------------------------------------------------------- policies (Q1)
+def parse_policies(spec):
+    """Returns a list of dicts sorted like the reference (stable, by treatment ordinal descending)."""
+    pols = []
+    for s in spec.split("-"):
+        if len(s) == 0:
+            continue
+        chars = list(s)
+        p = {"read_cat": None, "read_param": -1, "base_cats": [], "treatment": None, "param": None}
+
+        def read_param():
+            v = 0
+            while chars and chars[0].isdigit() and chars[0] in "0123456789":
+                v = v * 10 + (ord(chars.pop(0)) - 48)
+            return v
+
+        def read_treatment():
+            v = read_param()
+            if v == 0:
+                return ("DROP", 0)
+            if v == 40:
+                return ("PRESERVE", 40)
+            return ("BIN", v)
+
+        while chars:
+            code = chars.pop(0)
+            if code == "R":
+                p["base_cats"].append(("MATCH", -1))
+                p["treatment"], p["param"] = read_treatment()
+            elif code == "N":
+                p["base_cats"].append(("MISMATCH", -1))
+                p["treatment"], p["param"] = read_treatment()
+            elif code == "X":
+                p["base_cats"].append(("LOWER_COVERAGE", read_param()))
+            elif code == "D":
+                p["base_cats"].append(("FLANKING_DELETION", -1))
+                p["treatment"], p["param"] = read_treatment()
+            elif code == "M":
+                p["read_cat"], p["read_param"] = "HIGHER_MAPPING_SCORE", read_param()
+            elif code == "m":
+                p["read_cat"], p["read_param"] = "LOWER_MAPPING_SCORE", read_param()
+            elif code == "U":
+                p["read_cat"] = "UNPLACED"
+                p["treatment"], p["param"] = read_treatment()
+            elif code == "P":
+                p["base_cats"].append(("PILEUP", read_param()))
+                p["treatment"], p["param"] = read_treatment()
+            elif code == "I":
+                p["base_cats"].append(("INSERTION", -1))
+                p["treatment"], p["param"] = read_treatment()
+            elif code == "_":
+                p["treatment"], p["param"] = read_treatment()
+            elif code == "*":
+                p["read_cat"] = "ALL"
+                p["treatment"], p["param"] = read_treatment()
+            else:
+                raise RuntimeError("Unknown read or base category: " + code)
+            if p["treatment"] is None:
+                p["treatment"], p["param"] = "PRESERVE", 40
+        pols.append(p)
+    pols.sort(key=lambda q: -TREATMENTS[q["treatment"]])  # list.sort is stable
+    return pols
+
+
+def policies_to_c(pols):
+    arr = (Policy * max(len(pols), 1))()
+    for i, p in enumerate(pols):
+        arr[i].read_cat = READ_CATS[p["read_cat"]]
+        arr[i].read_param = p["read_param"]
+        arr[i].treatment = TREATMENTS[p["treatment"]]
+        arr[i].n_base_cat = len(p["base_cats"])
+        for k, (name, param) in enumerate(p["base_cats"]):
+            arr[i].base_cat[k] = BASE_CATS[name]
+            arr[i].base_param[k] = param
+    return arr
+
+
+# ---------------------------------------------------------------- record kernels
+_CIGAR_OPS = "MIDNSHP=X"
+
+
+def pack_cigar(text):
+    out, num = [], 0
+    for ch in text:
+        if ch.isdigit():
+            num = num * 10 + int(ch)
+        else:
+            out.append((num << 4) | _CIGAR_OPS.index(ch))
+            num = 0
+    return out
+
+
+def cigar_ref_len(packed):
+    return sum(int(c) >> 4 for c in packed if (int(c) & 15) in (0, 2, 3, 7, 8))
+
+
+class Reads:
+    """Flat reads of one container (same SoA layout as include/cramgpu.h)."""
+
+    def __init__(self, starts, cigars, bases, quals=None, mapq=None, rflags=None):
+        n = len(starts)
+        self.n = n
+        self.aln_start = np.asarray(starts, np.int32)
+        lens = [len(b) for b in bases]
+        self.read_len = np.asarray(lens, np.int32)
+        self.base_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+        self.bases = np.frombuffer(b"".join(bytes(b) for b in bases) + b"\0", np.uint8).copy()
+        if quals is None:
+            self.quals = np.zeros(self.bases.size, np.uint8)
+        else:
+            self.quals = np.frombuffer(b"".join(bytes(q) for q in quals) + b"\0", np.uint8).copy()
+        packed = [pack_cigar(c) if isinstance(c, str) else list(c) for c in cigars]
+        nc = [len(c) for c in packed]
+        self.n_cigar = np.asarray(nc, np.int32)
+        self.cigar_off = np.concatenate([[0], np.cumsum(nc)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+        self.cigar = np.asarray([x for c in packed for x in c] + [0], np.uint32)
+        self.aln_span = np.asarray([cigar_ref_len(c) - 1 for c in packed], np.int32)
+        self.mapq = np.asarray(mapq if mapq is not None else [60] * n, np.uint8)
+        self.rflags = np.asarray(rflags if rflags is not None else [0] * n, np.uint8)
+
+
+def extract_features(reads, ref, feat_cap=None):
+    ref = _u8(ref)
+    cap = int(feat_cap if feat_cap is not None else reads.bases.size + 4 * reads.cigar.size + 16)
+    f_op = np.zeros(cap, np.uint8)
+    f_pos = np.zeros(cap, np.int32)
+    f_a = np.zeros(cap, np.int32)
+    f_b = np.zeros(cap, np.int32)
+    feat_off = np.zeros(reads.n + 1, np.int64)
+    hist = np.zeros(25, np.int64)
+    n = lib().orc_extract_features(
+        ctypes.c_int32(reads.n), _p(reads.bases), _p(reads.base_off), _p(reads.read_len), _p(reads.aln_start),
+        _p(reads.rflags), _p(reads.cigar), _p(reads.cigar_off), _p(reads.n_cigar), _p(ref), ctypes.c_int64(ref.size),
+        ctypes.c_int64(cap), _p(f_op), _p(f_pos), _p(f_a), _p(f_b), _p(feat_off), _p(hist))
+    if n < 0:
+        raise RuntimeError("feature capacity too small")
+    return dict(op=f_op[:n], pos=f_pos[:n], a=f_a[:n], b=f_b[:n], off=feat_off, hist=hist)
+
+
+def substitution_matrix(hist):
+    hist = np.ascontiguousarray(hist, np.int64)
+    m = np.zeros(5, np.uint8)
+    lib().orc_substitution_matrix(_p(hist), _p(m))
+    return m
+
+
+def assign_codes(feats, matrix):
+    matrix = np.ascontiguousarray(matrix, np.uint8)
+    lib().orc_assign_codes(ctypes.c_int64(feats["op"].size), _p(feats["op"]), _p(feats["a"]), _p(matrix))
+
+
+def restore_bases(read_len, aln_start, rflags, feats, seq, seq_off, win, win_start0, matrix):
+    read_len = np.ascontiguousarray(read_len, np.int32)
+    aln_start = np.ascontiguousarray(aln_start, np.int32)
+    rflags = np.ascontiguousarray(rflags, np.uint8)
+    n = read_len.size
+    out_off = np.concatenate([[0], np.cumsum(read_len)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+    out = np.zeros(int(read_len.sum()) + 1, np.uint8)
+    status = np.zeros(n, np.int32)
+    win = _u8(win)
+    seq = _u8(seq) if seq is not None else np.zeros(1, np.uint8)
+    seq_off = np.ascontiguousarray(seq_off if seq_off is not None else np.zeros(n), np.int64)
+    matrix = np.ascontiguousarray(matrix, np.uint8)
+    op = np.ascontiguousarray(feats["op"], np.uint8)
+    pos = np.ascontiguousarray(feats["pos"], np.int32)
+    a = np.ascontiguousarray(feats["a"], np.int32)
+    b = np.ascontiguousarray(feats["b"], np.int32)
+    off = np.ascontiguousarray(feats["off"], np.int64)
+    lib().orc_restore_bases(ctypes.c_int32(n), _p(read_len), _p(aln_start), _p(rflags), _p(off), _p(op), _p(pos),
+                            _p(a), _p(b), _p(seq), _p(seq_off), _p(win), ctypes.c_int64(win.size),
+                            ctypes.c_int64(win_start0), _p(matrix), _p(out), _p(out_off), _p(status))
+    return out[:-1], out_off, status
+
+
+def restore_quals(read_len, rflags, feats, scores, default_qs=30):
+    read_len = np.ascontiguousarray(read_len, np.int32)
+    rflags = np.ascontiguousarray(rflags, np.uint8)
+    n = read_len.size
+    out_off = np.concatenate([[0], np.cumsum(read_len)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+    sc = np.ascontiguousarray(scores, np.uint8).copy()
+    status = np.zeros(n, np.int32)
+    op = np.ascontiguousarray(feats["op"], np.uint8)
+    pos = np.ascontiguousarray(feats["pos"], np.int32)
+    a = np.ascontiguousarray(feats["a"], np.int32)
+    b = np.ascontiguousarray(feats["b"], np.int32)
+    off = np.ascontiguousarray(feats["off"], np.int64)
+    lib().orc_restore_quals(ctypes.c_int32(n), _p(read_len), _p(rflags), _p(off), _p(op), _p(pos), _p(a), _p(b),
+                            ctypes.c_uint8(default_qs), _p(sc), _p(out_off), _p(status))
+    return sc, status
+
+
+def tracks_windows(reads, pols, ref_len, window=1000000):
+    arr = policies_to_c(pols)
+    wpos = np.zeros(reads.n, np.int32)
+    r = lib().orc_tracks_windows(ctypes.c_int32(reads.n), _p(reads.aln_start), _p(reads.aln_span), _p(reads.rflags),
+                                 _p(reads.mapq), arr, ctypes.c_int32(len(pols)), ctypes.c_int64(ref_len),
+                                 ctypes.c_int32(window), _p(wpos))
+    if r < 0:
+        raise RuntimeError("ReferenceTracks would throw at read %d" % (-r - 1))
+    return wpos
+
+
+def lossy_quals(reads, ref, pols, window=1000000, wpos=None):
+    ref = _u8(ref)
+    arr = policies_to_c(pols)
+    if wpos is None:
+        wpos = tracks_windows(reads, pols, ref.size, window)
+    scores = np.zeros(reads.bases.size, np.uint8)
+    force = np.zeros(reads.n, np.uint8)
+    status = np.zeros(reads.n, np.int32)
+    r = lib().orc_lossy_quals(ctypes.c_int32(reads.n), _p(reads.bases), _p(reads.quals), _p(reads.base_off),
+                              _p(reads.read_len), _p(reads.aln_start), _p(reads.rflags), _p(reads.mapq),
+                              _p(reads.cigar), _p(reads.cigar_off), _p(reads.n_cigar), _p(ref),
+                              ctypes.c_int64(ref.size), _p(wpos), ctypes.c_int32(window), arr,
+                              ctypes.c_int32(len(pols)), _p(scores), _p(force), _p(status))
+    if r < 0:
+        raise RuntimeError("oracle lossy_quals error %d" % r)
+    return scores, force, status
+
+
+def merge_quality_features(reads, scores, force, qstatus, feats):
+    cap = int(feats["op"].size + reads.bases.size + 1)
+    m_op = np.zeros(cap, np.uint8)
+    m_pos = np.zeros(cap, np.int32)
+    m_a = np.zeros(cap, np.int32)
+    m_b = np.zeros(cap, np.int32)
+    m_off = np.zeros(reads.n + 1, np.int64)
+    op = np.ascontiguousarray(feats["op"], np.uint8)
+    pos = np.ascontiguousarray(feats["pos"], np.int32)
+    a = np.ascontiguousarray(feats["a"], np.int32)
+    b = np.ascontiguousarray(feats["b"], np.int32)
+    off = np.ascontiguousarray(feats["off"], np.int64)
+    n = lib().orc_merge_quality_features(
+        ctypes.c_int32(reads.n), _p(reads.read_len), _p(reads.base_off), _p(scores), _p(force), _p(qstatus), _p(off),
+        _p(op), _p(pos), _p(a), _p(b), ctypes.c_int64(cap), _p(m_op), _p(m_pos), _p(m_a), _p(m_b), _p(m_off))
+    if n < 0:
+        raise RuntimeError("merge capacity too small")
+    return dict(op=m_op[:n], pos=m_pos[:n], a=m_a[:n], b=m_b[:n], off=m_off)
