@@ -1,0 +1,132 @@
+"""ctypes binding of libcramgpu.so (C ABI: include/cramgpu.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C cramtools_amd/csrc`.  There is no fallback:
+a missing library raises ImportError-like RuntimeError, a missing GPU makes every compute call fail with
+CRAMGPU_E_NO_DEVICE.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcramgpu.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+E_INPUT_LENGTH, E_OUT_TOO_SMALL, E_INSUFFICIENT, E_ORDER, E_CORRUPT = -1, -2, -3, -4, -5
+E_ARG, E_HIP, E_NO_DEVICE, E_JAVA_THROWS = -6, -7, -8, -9
+ARENA_ALIGN = 16
+RF_UNMAPPED, RF_NULL_QUALS, RF_NO_BASES, RF_UNKNOWN_BASES, RF_FORCE_QS, RF_SKIP = 1, 2, 4, 8, 16, 32
+
+# the reference's exception messages
+MESSAGES = {
+    E_INPUT_LENGTH: "Incorrect input length.",
+    E_OUT_TOO_SMALL: "Output buffer too small to fit the raw bytes.",
+    E_INSUFFICIENT: "Insufficient buffer size.",
+    E_ORDER: "Unknown rANS order",
+    E_CORRUPT: "Malformed rANS stream",
+    E_ARG: "Bad argument",
+    E_HIP: "HIP runtime error",
+    E_NO_DEVICE: "No MI355X device visible (libcramgpu has no CPU path)",
+    E_JAVA_THROWS: "The reference would throw on this record",
+}
+
+
+class CramGpuError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = MESSAGES.get(code, "error %d" % code)
+        super().__init__(msg + (": " + detail if detail else ""))
+
+
+class Block(C.Structure):
+    _fields_ = [("in_off", C.c_int64), ("out_off", C.c_int64), ("in_len", C.c_int32), ("out_cap", C.c_int32),
+                ("order", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RefWin(C.Structure):
+    _fields_ = [("ref_off", C.c_int64), ("ref_len", C.c_int64), ("ref_start0", C.c_int64)]
+
+
+class Reads(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_cont", C.c_int32), ("n_bases", C.c_int64), ("max_read_len", C.c_int32),
+                ("reserved", C.c_int32), ("bases", C.c_void_p), ("quals", C.c_void_p), ("base_off", C.c_void_p),
+                ("read_len", C.c_void_p), ("aln_start", C.c_void_p), ("rflags", C.c_void_p), ("mapq", C.c_void_p),
+                ("cigar", C.c_void_p), ("cigar_off", C.c_void_p), ("n_cigar", C.c_void_p), ("read_cont", C.c_void_p),
+                ("win", C.c_void_p)]
+
+
+class Features(C.Structure):
+    _fields_ = [("op", C.c_void_p), ("pos", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("off", C.c_void_p),
+                ("cap", C.c_int64)]
+
+
+class Policy(C.Structure):
+    _fields_ = [("read_cat", C.c_int32), ("read_param", C.c_int32), ("treatment", C.c_int32), ("n_base_cat", C.c_int32),
+                ("base_cat", C.c_int32 * 8), ("base_param", C.c_int32 * 8)]
+
+
+# every symbol include/cramgpu.h declares: name -> (restype, argtypes)
+P, I32, I64, U8 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint8
+SYMBOLS = {
+    "cramgpu_open": (P, [I32]),
+    "cramgpu_close": (None, [P]),
+    "cramgpu_last_error": (C.c_char_p, []),
+    "cramgpu_device_count": (I32, []),
+    "cramgpu_info": (I32, [P, P, P]),
+    "cramgpu_rans_bound": (I32, [I32]),
+    "cramgpu_rans_compress": (I32, [P, I32, I32, P, I32]),
+    "cramgpu_rans_uncompress": (I32, [P, I32, P, I32]),
+    "cramgpu_rans_raw_size": (I32, [P, I32]),
+    "cramgpu_rans_encode_dev": (I32, [P, P, P, P, I32, P, P, P]),
+    "cramgpu_rans_decode_dev": (I32, [P, P, P, P, I32, P, P]),
+    "cramgpu_gather_dev": (I32, [P, P, P, P, I32, I32, I32, P, I64, P, P]),
+    "cramgpu_rans_encode_batch": (I32, [P, P, I64, P, I64, P, I32, P]),
+    "cramgpu_rans_decode_batch": (I32, [P, P, I64, P, I64, P, I32, P]),
+    "cramgpu_extract_features_dev": (I64, [P, P, P, P, P, P]),
+    "cramgpu_substitution_matrix": (None, [P, P]),
+    "cramgpu_assign_codes_dev": (I32, [P, I32, P, I32, P, P, P]),
+    "cramgpu_restore_bases_dev": (I32, [P, I32, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P]),
+    "cramgpu_restore_quals_dev": (I32, [P, I32, P, P, P, U8, P, P, P, P]),
+    "cramgpu_parse_policies": (I32, [C.c_char_p, P, I32]),
+    "cramgpu_lossy_quals_dev": (I32, [P, P, P, P, I32, P, I32, P, P, P, P]),
+    "cramgpu_tracks_windows": (I32, [I32, P, P, P, P, P, I32, I64, I32, P]),
+    "cramgpu_merge_quality_features_dev": (I64, [P, I32, P, P, P, P, P, P, P, P]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libcramgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "cramgpu.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", CSRC, "-j8", "-s"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libcramgpu.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                               "cramtools_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return (lib().cramgpu_last_error() or b"").decode(errors="replace")
+
+
+def check(rc):
+    if rc < 0:
+        raise CramGpuError(int(rc), last_error())
+    return rc

@@ -1,0 +1,652 @@
+// Host side of libcramgpu.so: contexts, staging, launches.  C ABI declared in include/cramgpu.h.
+// There is deliberately no CPU implementation of any kernel here: without a gfx950 device every compute entry
+// point fails with CRAMGPU_E_NO_DEVICE / CRAMGPU_E_HIP.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                              \
+    do {                                                          \
+        hipError_t _e = (expr);                                   \
+        if (_e != hipSuccess) return fail(CRAMGPU_E_HIP, #expr, _e); \
+    } while (0)
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(n, (size_t)1024);
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+template <class T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(n, (size_t)1024);
+        hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct cramgpu_ctx {
+    int device = 0;
+    int n_cu = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t staged = nullptr;  // completion of the last descriptor upload (pinned staging reuse)
+    bool staged_pending = false;
+    std::mutex mu;
+    // rANS launch geometry
+    int tab_bytes = 0, enc_wpc = 0, dec_wpc = 0, n_waves_enc = 0, n_waves_dec = 0;
+    size_t enc_lds = 0, dec_lds = 0;
+    DevBuf<uint8_t> enc_gs, dec_gs;
+    DevBuf<uint32_t> rcp_tab, tickets;
+    uint32_t ticket_next = 0;
+    // descriptor staging
+    PinBuf<cramgpu_block> h_desc;
+    PinBuf<int32_t> h_perm;
+    DevBuf<cramgpu_block> d_desc;
+    DevBuf<int32_t> d_perm;
+    // host-batch / level-0 staging
+    DevBuf<uint8_t> d_in, d_out, d_pack;
+    DevBuf<int32_t> d_len;
+    DevBuf<int64_t> d_pos, d_off;
+    DevBuf<int32_t> d_err;
+    PinBuf<uint8_t> h_stage;
+    PinBuf<int32_t> h_len;
+    PinBuf<int64_t> h_off;
+    // record kernels
+    DevBuf<int32_t> d_counts;
+    DevBuf<int64_t> d_total;
+    PinBuf<int64_t> h_total;
+    DevBuf<uint8_t> d_small;   // matrix tables, policies
+    DevBuf<uint8_t> d_maskws;
+};
+
+namespace {
+
+constexpr int kTicketSlots = 256;
+
+hipStream_t pick(cramgpu_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+// uploads descriptors + LPT permutation, returns device pointers valid in stream order
+int stage_blocks(cramgpu_ctx* c, const cramgpu_block* blocks, int32_t n, hipStream_t s, bool encode) {
+    if (c->staged_pending) {
+        HIPCHK(hipEventSynchronize(c->staged));
+        c->staged_pending = false;
+    }
+    HIPCHK(c->h_desc.reserve(n));
+    HIPCHK(c->h_perm.reserve(n));
+    HIPCHK(c->d_desc.reserve(n));
+    HIPCHK(c->d_perm.reserve(n));
+    for (int32_t i = 0; i < n; i++) {
+        const cramgpu_block& b = blocks[i];
+        if (b.in_off < 0 || b.out_off < 0 || (b.in_off % CRAMGPU_ARENA_ALIGN) || (encode && (b.out_off % CRAMGPU_ARENA_ALIGN)))
+            return fail(CRAMGPU_E_ARG, "block offsets must be non-negative multiples of CRAMGPU_ARENA_ALIGN");
+        if (b.in_len < 0 || b.out_cap < 0) return fail(CRAMGPU_E_ARG, "negative block size");
+    }
+    memcpy(c->h_desc.p, blocks, (size_t)n * sizeof(cramgpu_block));
+    std::iota(c->h_perm.p, c->h_perm.p + n, 0);
+    std::stable_sort(c->h_perm.p, c->h_perm.p + n,
+                     [&](int32_t x, int32_t y) { return blocks[x].in_len > blocks[y].in_len; });
+    HIPCHK(hipMemcpyAsync(c->d_desc.p, c->h_desc.p, (size_t)n * sizeof(cramgpu_block), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_perm.p, c->h_perm.p, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(c->staged, s));
+    c->staged_pending = true;
+    return 0;
+}
+
+int rans_run(cramgpu_ctx* c, bool encode, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks, int32_t n,
+             int32_t* d_out_len, int64_t* d_out_pos, hipStream_t s) {
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = stage_blocks(c, blocks, n, s, encode);
+    if (rc) return rc;
+    uint32_t* ticket = c->tickets.p + (c->ticket_next++ % kTicketSlots);
+    HIPCHK(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
+    RansArgs a{};
+    a.in = d_in;
+    a.out = d_out;
+    a.desc = c->d_desc.p;
+    a.perm = c->d_perm.p;
+    a.n_blocks = n;
+    a.out_len = d_out_len;
+    a.out_pos = d_out_pos;
+    a.ticket = ticket;
+    a.rcp_tab = c->rcp_tab.p;
+    a.tab_bytes = c->tab_bytes;
+    if (encode) {
+        a.gscratch = c->enc_gs.p;
+        HIPCHK(launch_rans_encode(a, std::min(n, c->n_waves_enc), c->enc_lds, s));
+    } else {
+        a.gscratch = c->dec_gs.p;
+        HIPCHK(launch_rans_decode(a, std::min(n, c->n_waves_dec), c->dec_lds, s));
+    }
+    return 0;
+}
+
+std::mutex g_default_mu;
+cramgpu_ctx* g_default = nullptr;
+
+cramgpu_ctx* default_ctx() {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default) g_default = cramgpu_open(0);
+    return g_default;
+}
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) & ~(a - 1); }
+
+}  // namespace
+
+extern "C" {
+
+const char* cramgpu_last_error(void) { return g_err.c_str(); }
+
+int32_t cramgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+cramgpu_ctx* cramgpu_open(int32_t device_index) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_index < 0 || device_index >= n) {
+        fail(CRAMGPU_E_NO_DEVICE, "cramgpu_open: no such HIP device (libcramgpu has no CPU path)");
+        return nullptr;
+    }
+    if (hipSetDevice(device_index) != hipSuccess) {
+        fail(CRAMGPU_E_HIP, "hipSetDevice failed");
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_index) != hipSuccess) {
+        fail(CRAMGPU_E_HIP, "hipGetDeviceProperties failed");
+        return nullptr;
+    }
+    cramgpu_ctx* c = new cramgpu_ctx();
+    c->device = device_index;
+    c->n_cu = prop.multiProcessorCount;
+    const int lds_per_cu = 160 * 1024;
+    c->tab_bytes = env_int("CRAMGPU_TAB_BYTES", 24 * 1024) & ~15;
+    if (c->tab_bytes < 20 * 1024) c->tab_bytes = 20 * 1024;  // order-0 decode needs a 16 KiB slot table
+    c->enc_lds = rans_encode_fixed_lds() + c->tab_bytes;
+    c->dec_lds = rans_decode_fixed_lds() + c->tab_bytes;
+    c->enc_wpc = std::max(1, std::min(env_int("CRAMGPU_ENC_WAVES_PER_CU", 16), (int)(lds_per_cu / (c->enc_lds + 512))));
+    c->dec_wpc = std::max(1, std::min(env_int("CRAMGPU_DEC_WAVES_PER_CU", 16), (int)(lds_per_cu / (c->dec_lds + 512))));
+    c->n_waves_enc = c->n_cu * c->enc_wpc;
+    c->n_waves_dec = c->n_cu * c->dec_wpc;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->staged, hipEventDisableTiming) == hipSuccess &&
+              c->enc_gs.reserve((size_t)c->n_waves_enc * ENC_GSCRATCH_BYTES) == hipSuccess &&
+              c->dec_gs.reserve((size_t)c->n_waves_dec * DEC_GSCRATCH_BYTES) == hipSuccess &&
+              c->rcp_tab.reserve(4096) == hipSuccess && c->tickets.reserve(kTicketSlots) == hipSuccess &&
+              c->d_err.reserve(16) == hipSuccess && c->d_total.reserve(16) == hipSuccess &&
+              c->h_total.reserve(16) == hipSuccess && c->d_small.reserve(65536) == hipSuccess;
+    if (ok) ok = launch_rcp_init(c->rcp_tab.p, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+    if (!ok) {
+        fail(CRAMGPU_E_HIP, "cramgpu_open: allocation or init kernel failed", hipGetLastError());
+        cramgpu_close(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void cramgpu_close(cramgpu_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->enc_gs.release(); c->dec_gs.release(); c->rcp_tab.release(); c->tickets.release();
+    c->h_desc.release(); c->h_perm.release(); c->d_desc.release(); c->d_perm.release();
+    c->d_in.release(); c->d_out.release(); c->d_pack.release(); c->d_len.release(); c->d_pos.release();
+    c->d_off.release(); c->d_err.release(); c->h_stage.release(); c->h_len.release(); c->h_off.release();
+    c->d_counts.release(); c->d_total.release(); c->h_total.release(); c->d_small.release(); c->d_maskws.release();
+    if (c->staged) (void)hipEventDestroy(c->staged);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int32_t cramgpu_info(cramgpu_ctx* c, int32_t* n_cu, int32_t* n_waves) {
+    if (!c) return fail(CRAMGPU_E_ARG, "null context");
+    if (n_cu) *n_cu = c->n_cu;
+    if (n_waves) *n_waves = c->n_waves_enc;
+    return 0;
+}
+
+int32_t cramgpu_rans_bound(int32_t n) { return (int32_t)(1.05 * (double)n + 257.0 * 257.0 * 3.0 + 4.0); }
+
+int32_t cramgpu_rans_raw_size(const uint8_t* in, int32_t n) {
+    if (n == 0) return 0;
+    if (!in || n < 9) return CRAMGPU_E_INPUT_LENGTH;
+    return (int32_t)((uint32_t)in[5] | ((uint32_t)in[6] << 8) | ((uint32_t)in[7] << 16) | ((uint32_t)in[8] << 24));
+}
+
+int32_t cramgpu_rans_encode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,
+                                int32_t n, int32_t* d_out_len, int64_t* d_out_pos, void* stream) {
+    if (!c || n < 0 || (n > 0 && (!d_in || !d_out || !blocks || !d_out_len || !d_out_pos)))
+        return fail(CRAMGPU_E_ARG, "cramgpu_rans_encode_dev: bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    return rans_run(c, true, d_in, d_out, blocks, n, d_out_len, d_out_pos, pick(c, stream));
+}
+
+int32_t cramgpu_rans_decode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,
+                                int32_t n, int32_t* d_out_len, void* stream) {
+    if (!c || n < 0 || (n > 0 && (!d_in || !d_out || !blocks || !d_out_len)))
+        return fail(CRAMGPU_E_ARG, "cramgpu_rans_decode_dev: bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    return rans_run(c, false, d_in, d_out, blocks, n, d_out_len, nullptr, pick(c, stream));
+}
+
+int32_t cramgpu_gather_dev(cramgpu_ctx* c, const uint8_t* d_src, const int64_t* d_pos, const int32_t* d_len, int32_t n,
+                           int32_t max_len, int32_t align, uint8_t* d_dst, int64_t dst_cap, int64_t* d_dst_off,
+                           void* stream) {
+    if (!c || n < 0 || max_len < 0 || align < 1 || (align & (align - 1)) || (n > 0 && (!d_src || !d_pos || !d_len || !d_dst || !d_dst_off)))
+        return fail(CRAMGPU_E_ARG, "cramgpu_gather_dev: bad argument");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(launch_gather(d_src, d_pos, d_len, n, align, d_dst, dst_cap, d_dst_off, c->d_err.p, max_len, pick(c, stream)));
+    return 0;
+}
+
+// ---- host-arena batches ----
+static int32_t host_batch(cramgpu_ctx* c, bool encode, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                          int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len) {
+    if (!c || n < 0 || in_bytes < 0 || out_bytes < 0 || (n > 0 && (!in_arena || !out_arena || !blocks || !out_len)))
+        return fail(CRAMGPU_E_ARG, "batch: bad argument");
+    if (n == 0) return 0;
+    int64_t max_cap = 0;
+    for (int32_t i = 0; i < n; i++) {
+        if (blocks[i].in_off + blocks[i].in_len > in_bytes || blocks[i].out_off + blocks[i].out_cap > out_bytes)
+            return fail(CRAMGPU_E_ARG, "batch: block outside its arena");
+        max_cap = std::max<int64_t>(max_cap, blocks[i].out_cap);
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIPCHK(c->d_in.reserve((size_t)align_up(in_bytes, 16) + 16));
+    HIPCHK(c->d_out.reserve((size_t)align_up(out_bytes, 16) + 16));
+    HIPCHK(c->d_len.reserve(n));
+    HIPCHK(c->h_len.reserve(n));
+    HIPCHK(hipMemcpyAsync(c->d_in.p, in_arena, (size_t)in_bytes, hipMemcpyHostToDevice, s));
+    if (!encode) {
+        int rc = rans_run(c, false, c->d_in.p, c->d_out.p, blocks, n, c->d_len.p, nullptr, s);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->h_len.p, c->d_len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        // copy back each decoded block (ranges may be sparse inside the arena)
+        for (int32_t i = 0; i < n; i++) {
+            out_len[i] = c->h_len.p[i];
+            if (out_len[i] > 0)
+                HIPCHK(hipMemcpyAsync(out_arena + blocks[i].out_off, c->d_out.p + blocks[i].out_off, (size_t)out_len[i],
+                                      hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+    }
+    HIPCHK(c->d_pos.reserve(n));
+    HIPCHK(c->d_off.reserve((size_t)n + 1));
+    HIPCHK(c->h_off.reserve((size_t)n + 1));
+    int rc = rans_run(c, true, c->d_in.p, c->d_out.p, blocks, n, c->d_len.p, c->d_pos.p, s);
+    if (rc) return rc;
+    // pack on the device so that only compressed bytes cross PCIe
+    HIPCHK(c->d_pack.reserve((size_t)align_up(out_bytes, 16) + (size_t)n * 16 + 16));
+    HIPCHK(launch_gather(c->d_out.p, c->d_pos.p, c->d_len.p, n, 16, c->d_pack.p, (int64_t)c->d_pack.cap, c->d_off.p,
+                         c->d_err.p, (int32_t)std::min<int64_t>(max_cap, 0x7fffffff), s));
+    HIPCHK(hipMemcpyAsync(c->h_len.p, c->d_len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(c->h_off.p, c->d_off.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int64_t packed = c->h_off.p[n];
+    HIPCHK(c->h_stage.reserve((size_t)packed + 16));
+    HIPCHK(hipMemcpyAsync(c->h_stage.p, c->d_pack.p, (size_t)packed, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int32_t i = 0; i < n; i++) {
+        out_len[i] = c->h_len.p[i];
+        if (out_len[i] > 0) memcpy(out_arena + blocks[i].out_off, c->h_stage.p + c->h_off.p[i], (size_t)out_len[i]);
+    }
+    return 0;
+}
+
+int32_t cramgpu_rans_encode_batch(cramgpu_ctx* c, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                                  int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len) {
+    return host_batch(c, true, in_arena, in_bytes, out_arena, out_bytes, blocks, n, out_len);
+}
+int32_t cramgpu_rans_decode_batch(cramgpu_ctx* c, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                                  int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len) {
+    return host_batch(c, false, in_arena, in_bytes, out_arena, out_bytes, blocks, n, out_len);
+}
+
+// ---- level 0 ----
+int32_t cramgpu_rans_compress(const uint8_t* in, int32_t n, int32_t order, uint8_t* out, int32_t cap) {
+    if (order != 0 && order != 1) return fail(CRAMGPU_E_ORDER, "Unknown rANS order");
+    if (n == 0) return 0;
+    if (!in || !out || n < 0 || cap < 0) return fail(CRAMGPU_E_ARG, "cramgpu_rans_compress: bad argument");
+    cramgpu_ctx* c = default_ctx();
+    if (!c) return CRAMGPU_E_NO_DEVICE;
+    // RANS#allocateIfNeeded: the reference codes into its own bound-sized buffer and hands back an exact-size array
+    const int32_t bound = cramgpu_rans_bound(n);
+    cramgpu_block b{0, 0, n, bound, order, 0};
+    std::vector<uint8_t> tmp((size_t)bound);
+    int32_t len = 0;
+    int rc = host_batch(c, true, in, n, tmp.data(), bound, &b, 1, &len);
+    if (rc) return rc;
+    if (len < 0) return fail(len, "rans compress failed");
+    if (len > cap) return fail(CRAMGPU_E_INSUFFICIENT, "Insufficient buffer size.");
+    memcpy(out, tmp.data(), (size_t)len);
+    return len;
+}
+
+int32_t cramgpu_rans_uncompress(const uint8_t* in, int32_t n, uint8_t* out, int32_t cap) {
+    if (n == 0) return 0;
+    if (!in || n < 0 || cap < 0) return fail(CRAMGPU_E_ARG, "cramgpu_rans_uncompress: bad argument");
+    if (n < 9) return fail(CRAMGPU_E_INPUT_LENGTH, "Incorrect input length.");
+    cramgpu_ctx* c = default_ctx();
+    if (!c) return CRAMGPU_E_NO_DEVICE;
+    cramgpu_block b{0, 0, n, cap, 0, 0};
+    int32_t len = 0;
+    std::vector<uint8_t> dummy(1);
+    int rc = host_batch(c, false, in, n, cap > 0 && out ? out : dummy.data(), cap, &b, 1, &len);
+    if (rc) return rc;
+    if (len < 0) return fail(len, "rans uncompress failed");
+    return len;
+}
+
+// =====================================================================================================
+// Level 2 — record kernels
+// =====================================================================================================
+
+// SubstitutionMatrix#<init>([[J) L38-57: rank the four other bases by descending count, ties in ACGTN order
+void cramgpu_substitution_matrix(const int64_t* hist, uint8_t* matrix5) {
+    for (int r = 0; r < 5; r++) {
+        int others[4], k = 0;
+        for (int b = 0; b < 5; b++)
+            if (b != r) others[k++] = b;
+        int order[4] = {0, 1, 2, 3};
+        std::stable_sort(order, order + 4, [&](int x, int y) { return hist[r * 5 + others[x]] > hist[r * 5 + others[y]]; });
+        int rank[4];
+        for (int i = 0; i < 4; i++) rank[order[i]] = i;
+        matrix5[r] = (uint8_t)((rank[0] << 6) | (rank[1] << 4) | (rank[2] << 2) | rank[3]);
+    }
+}
+
+// SubstitutionMatrix#code / #base as tables: codes[5][256] (0 for bases outside ACGTN) and basesof[5][4]
+static void matrix_tables(const uint8_t* m5, uint8_t* codes, uint8_t* basesof) {
+    static const uint8_t ACGTN[5] = {'A', 'C', 'G', 'T', 'N'};
+    memset(codes, 0, 5 * 256);
+    for (int r = 0; r < 5; r++) {
+        int k = 0;
+        for (int b = 0; b < 5; b++) {
+            if (b == r) continue;
+            const int code = (m5[r] >> (6 - 2 * k)) & 3;
+            codes[r * 256 + ACGTN[b]] = (uint8_t)code;
+            basesof[r * 4 + code] = ACGTN[b];
+            k++;
+        }
+    }
+}
+
+static int upload_small(cramgpu_ctx* c, const void* src, size_t bytes, hipStream_t s) {
+    // synchronous with respect to the host buffer: small tables only
+    HIPCHK(c->d_small.reserve(bytes));
+    HIPCHK(hipMemcpyAsync(c->d_small.p, src, bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int64_t cramgpu_extract_features_dev(cramgpu_ctx* c, const cramgpu_reads* reads, const uint8_t* d_ref,
+                                     cramgpu_features* feats, int64_t* d_sub_hist, void* stream) {
+    if (!c || !reads || !feats || reads->n_reads < 0 || !feats->off) return fail(CRAMGPU_E_ARG, "extract_features: bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    const int32_t n = reads->n_reads;
+    HIPCHK(c->d_counts.reserve((size_t)n + 1));
+    if (n > 0) HIPCHK(launch_extract_features(*reads, d_ref, *feats, nullptr, c->d_counts.p, false, s));
+    HIPCHK(launch_feature_scan(n, c->d_counts.p, feats->off, c->d_total.p, s));
+    HIPCHK(hipMemcpyAsync(c->h_total.p, c->d_total.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int64_t total = c->h_total.p[0];
+    if (total > feats->cap) return fail(CRAMGPU_E_INSUFFICIENT, "extract_features: feature capacity too small");
+    if (n > 0 && total > 0) HIPCHK(launch_extract_features(*reads, d_ref, *feats, d_sub_hist, c->d_counts.p, true, s));
+    return total;
+}
+
+int32_t cramgpu_assign_codes_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_cont, int32_t n_cont,
+                                 const cramgpu_features* feats, const uint8_t* matrices, void* stream) {
+    if (!c || !feats || !matrices || n_reads < 0 || n_cont < 1) return fail(CRAMGPU_E_ARG, "assign_codes: bad argument");
+    if (n_reads == 0) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    std::vector<uint8_t> codes((size_t)n_cont * 5 * 256), tmp(20);
+    for (int i = 0; i < n_cont; i++) matrix_tables(matrices + 5 * i, codes.data() + (size_t)i * 5 * 256, tmp.data());
+    int rc = upload_small(c, codes.data(), codes.size(), s);
+    if (rc) return rc;
+    HIPCHK(launch_assign_codes(n_reads, d_read_cont, feats->off, feats->op, feats->a, c->d_small.p, s));
+    HIPCHK(hipStreamSynchronize(s));  // d_small is reused by the next call
+    return 0;
+}
+
+int32_t cramgpu_restore_bases_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_len, const int32_t* d_aln_start,
+                                  const uint8_t* d_rflags, const int32_t* d_read_cont, int32_t n_cont,
+                                  const cramgpu_refwin* d_wins, const cramgpu_features* feats, const uint8_t* d_seq,
+                                  const int64_t* d_seq_off, const uint8_t* d_ref, const uint8_t* matrices, uint8_t* d_out,
+                                  const int64_t* d_out_off, int32_t* d_status, void* stream) {
+    if (!c || !feats || !matrices || n_reads < 0 || n_cont < 1) return fail(CRAMGPU_E_ARG, "restore_bases: bad argument");
+    if (n_reads == 0) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    std::vector<uint8_t> basesof((size_t)n_cont * 20), tmp(5 * 256);
+    for (int i = 0; i < n_cont; i++) matrix_tables(matrices + 5 * i, tmp.data(), basesof.data() + (size_t)i * 20);
+    int rc = upload_small(c, basesof.data(), basesof.size(), s);
+    if (rc) return rc;
+    HIPCHK(launch_restore_bases(n_reads, d_read_len, d_aln_start, d_rflags, d_read_cont, d_wins, *feats, d_seq, d_seq_off,
+                                d_ref, c->d_small.p, d_out, d_out_off, d_status, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int32_t cramgpu_restore_quals_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_len, const uint8_t* d_rflags,
+                                  const cramgpu_features* feats, uint8_t default_qs, uint8_t* d_scores,
+                                  const int64_t* d_out_off, int32_t* d_status, void* stream) {
+    if (!c || !feats || n_reads < 0) return fail(CRAMGPU_E_ARG, "restore_quals: bad argument");
+    if (n_reads == 0) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(launch_restore_quals(n_reads, d_read_len, d_rflags, *feats, default_qs, d_scores, d_out_off, d_status,
+                                pick(c, stream)));
+    return 0;
+}
+
+// QualityScorePreservation.parsePolicies :167-191, parseSinglePolicy :193-256, readParam :139-146, readTreatment :148-165
+int32_t cramgpu_parse_policies(const char* spec, cramgpu_policy* out, int32_t max_pol) {
+    if (!spec || !out || max_pol < 0) return fail(CRAMGPU_E_ARG, "parse_policies: bad argument");
+    std::vector<cramgpu_policy> pols;
+    const char* p = spec;
+    while (true) {
+        const char* e = strchr(p, '-');
+        std::string tok = e ? std::string(p, e) : std::string(p);
+        if (!tok.empty()) {  // String.split drops nothing in the middle, but an empty token parses to a no-op policy
+            cramgpu_policy pol{};
+            pol.read_param = -1;
+            int treatment = -1;
+            size_t i = 0;
+            auto read_param = [&]() {
+                int v = 0;
+                while (i < tok.size() && tok[i] >= '0' && tok[i] <= '9') v = v * 10 + (tok[i++] - '0');
+                return v;
+            };
+            auto read_treatment = [&]() {
+                const int v = read_param();
+                return v == 0 ? 2 : v == 40 ? 0 : 1;  // 0 -> DROP, 40 -> PRESERVE, anything else -> BIN
+            };
+            auto add_cat = [&](int cat, int param) {
+                if (pol.n_base_cat < 8) {
+                    pol.base_cat[pol.n_base_cat] = cat;
+                    pol.base_param[pol.n_base_cat] = param;
+                    pol.n_base_cat++;
+                }
+            };
+            while (i < tok.size()) {
+                const char code = tok[i++];
+                switch (code) {
+                    case 'R': add_cat(1, -1); treatment = read_treatment(); break;
+                    case 'N': add_cat(2, -1); treatment = read_treatment(); break;
+                    case 'X': add_cat(5, read_param()); break;
+                    case 'D': add_cat(3, -1); treatment = read_treatment(); break;
+                    case 'M': pol.read_cat = 2; pol.read_param = read_param(); break;
+                    case 'm': pol.read_cat = 3; pol.read_param = read_param(); break;
+                    case 'U': pol.read_cat = 1; treatment = read_treatment(); break;
+                    case 'P': add_cat(4, read_param()); treatment = read_treatment(); break;
+                    case 'I': add_cat(6, -1); treatment = read_treatment(); break;
+                    case '_': treatment = read_treatment(); break;
+                    case '*': pol.read_cat = 4; treatment = read_treatment(); break;
+                    default: return fail(CRAMGPU_E_ARG, "Unknown read or base category");
+                }
+                if (treatment < 0) treatment = 0;  // :249-250 default PRESERVE
+            }
+            pol.treatment = treatment < 0 ? 0 : treatment;
+            pols.push_back(pol);
+        }
+        if (!e) break;
+        p = e + 1;
+    }
+    // :178-188 Collections.sort (stable) by treatment ordinal, descending: DROP(2), BIN(1), PRESERVE(0)
+    std::stable_sort(pols.begin(), pols.end(), [](const cramgpu_policy& a, const cramgpu_policy& b) { return a.treatment > b.treatment; });
+    if ((int32_t)pols.size() > max_pol) return fail(CRAMGPU_E_INSUFFICIENT, "parse_policies: too many policies");
+    for (size_t k = 0; k < pols.size(); k++) out[k] = pols[k];
+    return (int32_t)pols.size();
+}
+
+static bool host_read_gate(const cramgpu_policy& p, bool unmapped, int mapq) {
+    switch (p.read_cat) {
+        case 0: case 4: return true;
+        case 1: return unmapped;
+        case 3: return mapq < p.read_param;
+        case 2: return mapq > p.read_param;
+        default: return false;
+    }
+}
+
+// ReferenceTracks.ensureRange :127-133 / moveForwardTo :87-119 replayed in read order
+int32_t cramgpu_tracks_windows(int32_t n_reads, const int32_t* aln_start, const int32_t* aln_span, const uint8_t* rflags,
+                               const uint8_t* mapq, const cramgpu_policy* pol, int32_t n_pol, int64_t ref_len,
+                               int32_t window, int32_t* wpos) {
+    const int64_t W = window < ref_len ? window : ref_len;
+    int64_t position = 1;
+    for (int32_t r = 0; r < n_reads; r++) {
+        wpos[r] = 0;
+        if (rflags[r] & (CRAMGPU_RF_NULL_QUALS | CRAMGPU_RF_SKIP)) continue;
+        bool need = false;
+        for (int k = 0; k < n_pol; k++)
+            if (pol[k].n_base_cat > 0 && host_read_gate(pol[k], (rflags[r] & CRAMGPU_RF_UNMAPPED) != 0, mapq[r])) need = true;
+        if (!need || aln_start[r] == 0) continue;
+        const int64_t start = aln_start[r];
+        if (start < position) return -(r + 1);
+        if (start + aln_span[r] > position + W) {
+            int64_t np = start;
+            if (np - 1 >= ref_len) return -(r + 1);
+            if (np > ref_len - W + 1) np = ref_len - W + 1;
+            position = np;
+        }
+        wpos[r] = (int32_t)position;
+    }
+    return 0;
+}
+
+int32_t cramgpu_lossy_quals_dev(cramgpu_ctx* c, const cramgpu_reads* reads, const uint8_t* d_ref, const int32_t* d_wpos,
+                                int32_t window, const cramgpu_policy* pol, int32_t n_pol, uint8_t* d_scores,
+                                uint8_t* d_force, int32_t* d_status, void* stream) {
+    if (!c || !reads || n_pol < 0 || (n_pol > 0 && !pol)) return fail(CRAMGPU_E_ARG, "lossy_quals: bad argument");
+    if (reads->n_reads == 0) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    cramgpu_policy dummy{};
+    int rc = upload_small(c, n_pol ? (const void*)pol : (const void*)&dummy, sizeof(cramgpu_policy) * (size_t)std::max(n_pol, 1), s);
+    if (rc) return rc;
+    // global mask scratch for reads longer than the LDS mask (sized by the caller-visible arena: not known here, so
+    // it is sized from the largest base offset + length, read back once)
+    if (reads->max_read_len < 0 || reads->n_bases < 0) return fail(CRAMGPU_E_ARG, "lossy_quals: n_bases / max_read_len unset");
+    HIPCHK(c->d_maskws.reserve(reads->max_read_len + 1 > 16384 ? (size_t)reads->n_bases + (size_t)reads->n_reads + 64 : 64));
+    HIPCHK(launch_lossy_quals(*reads, d_ref, d_wpos, window, (const cramgpu_policy*)c->d_small.p, n_pol, d_scores, d_force,
+                              d_status, c->d_maskws.p, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int64_t cramgpu_merge_quality_features_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_len,
+                                           const int64_t* d_base_off, const uint8_t* d_scores, const uint8_t* d_force,
+                                           const int32_t* d_qstatus, const cramgpu_features* in, cramgpu_features* out,
+                                           void* stream) {
+    if (!c || !in || !out || n_reads < 0 || !out->off) return fail(CRAMGPU_E_ARG, "merge_quality_features: bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    HIPCHK(c->d_counts.reserve((size_t)n_reads + 1));
+    if (n_reads > 0)
+        HIPCHK(launch_merge_quality(n_reads, d_read_len, d_base_off, d_scores, d_force, d_qstatus, *in, *out, c->d_counts.p,
+                                    false, s));
+    HIPCHK(launch_feature_scan(n_reads, c->d_counts.p, out->off, c->d_total.p, s));
+    HIPCHK(hipMemcpyAsync(c->h_total.p, c->d_total.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int64_t total = c->h_total.p[0];
+    if (total > out->cap) return fail(CRAMGPU_E_INSUFFICIENT, "merge_quality_features: capacity too small");
+    if (n_reads > 0 && total > 0)
+        HIPCHK(launch_merge_quality(n_reads, d_read_len, d_base_off, d_scores, d_force, d_qstatus, *in, *out, c->d_counts.p,
+                                    true, s));
+    return total;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// Internal declarations shared by the HIP translation units of libcramgpu (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cramgpu.h"
+
+#define RANS_TF_SHIFT 12
+#define RANS_TOTFREQ 4096
+#define RANS_BYTE_L (1u << 23)
+
+// global scratch of one resident rANS wave: order-1 tables that do not fit LDS
+//   encode: counts u32[256][256] (256 KiB) + packed symbols uint2[256][256] (512 KiB)
+//   decode: order-1 rows u32[256][256] (256 KiB)
+#define ENC_GSCRATCH_BYTES (768u * 1024u)
+#define DEC_GSCRATCH_BYTES (256u * 1024u)
+
+struct RansArgs {
+    const uint8_t* in;
+    uint8_t* out;
+    const cramgpu_block* desc;  // device copy of the descriptors
+    const int32_t* perm;        // blocks sorted by descending length (longest-processing-time first)
+    int32_t n_blocks;
+    int32_t* out_len;
+    int64_t* out_pos;           // encode only
+    uint32_t* ticket;           // work-queue head, zeroed before the launch
+    uint8_t* gscratch;          // n_waves x {ENC,DEC}_GSCRATCH_BYTES
+    const uint32_t* rcp_tab;    // [4096] Encoding#RansEncSymbolInit rcp_freq per freq
+    int32_t tab_bytes;          // bytes of the LDS table region
+};
+
+// launchers (defined in the .hip files)
+hipError_t launch_rans_encode(const RansArgs& a, int n_waves, size_t lds_bytes, hipStream_t s);
+hipError_t launch_rans_decode(const RansArgs& a, int n_waves, size_t lds_bytes, hipStream_t s);
+hipError_t launch_rcp_init(uint32_t* d_rcp_tab, hipStream_t s);
+size_t rans_encode_fixed_lds();
+size_t rans_decode_fixed_lds();
+hipError_t launch_gather(const uint8_t* src, const int64_t* pos, const int32_t* len, int32_t n, int32_t align,
+                         uint8_t* dst, int64_t dst_cap, int64_t* dst_off, int32_t* err, int32_t max_len,
+                         hipStream_t s);
+
+// record kernels
+hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
+                                   int32_t* d_counts, bool write_pass, hipStream_t s);
+hipError_t launch_feature_scan(int32_t n_reads, const int32_t* d_counts, int64_t* d_off, int64_t* d_total, hipStream_t s);
+hipError_t launch_assign_codes(int32_t n_reads, const int32_t* read_cont, const int64_t* off, const uint8_t* op,
+                               int32_t* a, const uint8_t* d_codes, hipStream_t s);
+hipError_t launch_restore_bases(int32_t n_reads, const int32_t* read_len, const int32_t* aln_start, const uint8_t* rflags,
+                                const int32_t* read_cont, const cramgpu_refwin* wins, cramgpu_features f,
+                                const uint8_t* seq, const int64_t* seq_off, const uint8_t* ref, const uint8_t* d_basesof,
+                                uint8_t* out, const int64_t* out_off, int32_t* status, hipStream_t s);
+hipError_t launch_restore_quals(int32_t n_reads, const int32_t* read_len, const uint8_t* rflags, cramgpu_features f,
+                                uint8_t default_qs, uint8_t* scores, const int64_t* out_off, int32_t* status,
+                                hipStream_t s);
+hipError_t launch_lossy_quals(const cramgpu_reads& r, const uint8_t* ref, const int32_t* wpos, int32_t window,
+                              const cramgpu_policy* d_pol, int32_t n_pol, uint8_t* scores, uint8_t* force,
+                              int32_t* status, uint8_t* d_mask_ws, hipStream_t s);
+hipError_t launch_merge_quality(int32_t n_reads, const int32_t* read_len, const int64_t* base_off, const uint8_t* scores,
+                                const uint8_t* force, const int32_t* qstatus, cramgpu_features in, cramgpu_features out,
+                                int32_t* d_counts, bool write_pass, hipStream_t s);

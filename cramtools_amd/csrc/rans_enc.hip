@@ -1,0 +1,643 @@
+// K1 — CRAM 3.0 rANS 4x8 encoder (order 0 and order 1) for gfx950, byte-identical to htsjdk 2.4.1.
+//
+// Reference (htsjdk!encoding/rans/*, original source lines):
+//   RANS#compress L60-73, #encode_order0_way4 L90-106, #encode_order1_way4 L111-127, #finalizeCompressed L132-142
+//   Frequencies#calcFrequencies_o0 L109-145, #calcFrequencies_o1 L149-193, #writeFrequencies_o0/o1 L215-244/269-328,
+//   #buildSyms_o0/o1 L197-211/248-265, Encoding#RansEncSymbolInit L21-43, #RansEncPutSymbol L46-71,
+//   E04#compress L12-57, E14#compress L13-86, Utils#reverse L7-33
+//
+// Execution model.  A CRAM block is one rANS stream whose four interleaved states form four strictly serial
+// dependency chains; byte identity forbids re-blocking, so the only parallelism inside a block is (a) the four
+// states and (b) everything that does not depend on the states.  The kernel is a resident grid of single-wave
+// workgroups that pull blocks (longest first) from a ticket counter.  For its block a wave
+//   1. histograms the input with all 64 lanes (LDS counters, lane-replicated for small alphabets),
+//   2. normalises, serialises the frequency table and builds packed encoder symbols, one table row per lane,
+//   3. encodes in batches of 16 steps: all 64 lanes fetch symbol/context bytes and expand the 64 encoder symbols
+//      of the batch into an LDS staging area; lanes 0-3 run the four state chains reading that area at fixed
+//      offsets and log the pre-renormalisation states; then all 64 lanes turn the logged states into output
+//      bytes, placed with a ballot/popcount prefix in the reference's emission order (state 3,2,1,0 per step).
+//      Bytes are written from the end of the block's slot downwards, which realises Utils#reverse for free.
+// Order-1 tables live in LDS over the compacted alphabet (present symbols + 0) when n*(n|1)*12 B fits the table
+// region, else in a per-wave global scratch over the full 256x256 alphabet.
+#include "internal.h"
+
+namespace {
+
+constexpr int kSteps = 16;  // steps per batch: 16 steps x 4 states = 64 lanes
+
+struct EncFixedLds {
+    uint4 stageA[64];     // x_max, x_max<<8 (saturated), rcp_freq, bias
+    uint2 stageB[64];     // cmpl_freq, rcp_shift-32
+    uint32_t xs[64];      // state of (step, lane) before the step
+    uint32_t rowT[256];   // order-1 row totals (0 = context absent)
+    uint32_t rowoff[256]; // serialised offset of each row
+    uint8_t dmap[256];    // byte value -> dense index
+    uint8_t syml[256];    // dense index -> byte value
+};
+
+__device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long w = __shfl_xor(v, o);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+// exclusive prefix sum over the 64 lanes; total = sum of all
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t& total) {
+    uint32_t x = v;
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o);
+        if (l >= o) x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+__device__ __forceinline__ uint32_t mbcnt(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Encoding#RansEncSymbolInit L21-43 packed in 8 bytes: x = rcp_freq, y = freq | bias<<12 | (rcp_shift-32)<<25
+__device__ __forceinline__ uint2 pack_symbol(int32_t freq, uint32_t start, const uint32_t* rcp_tab) {
+    uint32_t f = (uint32_t)freq & 4095u;
+    uint32_t rcp, bias, sh;
+    if (f < 2) {
+        rcp = ~0u;
+        sh = 0;
+        bias = start + 4095u;
+    } else {
+        uint32_t shift = 32u - (uint32_t)__clz((int)(f - 1));  // smallest shift with (1<<shift) >= f
+        rcp = rcp_tab[f];
+        sh = shift - 1;
+        bias = start;
+    }
+    return make_uint2(rcp, f | ((bias & 8191u) << 12) | (sh << 25));
+}
+
+// expand a packed symbol into the staged form the state lanes consume
+__device__ __forceinline__ void expand_symbol(uint2 e, uint4& A, uint2& B) {
+    uint32_t f = e.y & 4095u;
+    A.x = f << 19;                              // x_max = ((L >> 12) << 8) * freq
+    A.y = f < 16 ? (f << 27) : 0xFFFFFFFFu;     // second renormalisation byte iff x >= x_max << 8 (x < 2^31)
+    A.z = e.x;
+    A.w = (e.y >> 12) & 8191u;
+    B.x = 4096u - f;
+    B.y = e.y >> 25;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// phase 1: histograms
+// ---------------------------------------------------------------------------------------------------------
+// order-0 counts of src[0..n) into cnt[256] using R lane-replicated LDS histograms at rep (R*256 words)
+__device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* rep, int R) {
+    const int l = lane_id();
+    for (int i = l; i < R * 256; i += 64) rep[i] = 0;
+    __syncthreads();
+    uint32_t* my = rep + (l & (R - 1)) * 256;
+    const int32_t n16 = n & ~15;
+    for (int32_t i = l * 16; i < n16; i += 64 * 16) {
+        uint4 v = *reinterpret_cast<const uint4*>(src + i);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            atomicAdd(&my[w[k] & 255u], 1u);
+            atomicAdd(&my[(w[k] >> 8) & 255u], 1u);
+            atomicAdd(&my[(w[k] >> 16) & 255u], 1u);
+            atomicAdd(&my[w[k] >> 24], 1u);
+        }
+    }
+    if (n16 + l < n) atomicAdd(&my[src[n16 + l]], 1u);
+    __syncthreads();
+    for (int j = l; j < 256; j += 64) {
+        uint32_t s = 0;
+        for (int r = 0; r < R; r++) s += rep[r * 256 + j];
+        cnt[j] = s;
+    }
+    __syncthreads();
+}
+
+// order-1 pair counts: cnt[row(prev)*stride + col(cur)] with prev = 0 before the first byte
+// (Frequencies#calcFrequencies_o1 L149-168).  DENSE: indices through dmap (LDS tables); else raw bytes (global table).
+template <bool DENSE>
+__device__ void hist_o1(const uint8_t* src, int32_t n, uint32_t* cnt, int stride, const uint8_t* dmap, uint32_t* rep,
+                        int R, int rstride, int cells) {
+    const int l = lane_id();
+    uint32_t* my = cnt;
+    if (R > 1) {
+        for (int i = l; i < R * rstride; i += 64) rep[i] = 0;
+        my = rep + (l & (R - 1)) * rstride;
+    }
+    __syncthreads();
+    const int32_t n16 = n & ~15;
+    for (int32_t i = l * 16; i < n16; i += 64 * 16) {
+        uint4 v = *reinterpret_cast<const uint4*>(src + i);
+        uint32_t prev = i ? src[i - 1] : 0u;
+        uint32_t row = (DENSE ? (uint32_t)dmap[prev] : prev) * (uint32_t)stride;
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int bshift = 0; bshift < 32; bshift += 8) {
+                uint32_t c = (w[k] >> bshift) & 255u;
+                uint32_t col = DENSE ? (uint32_t)dmap[c] : c;
+                atomicAdd(&my[row + col], 1u);
+                row = col * (uint32_t)stride;
+            }
+        }
+    }
+    if (n16 + l < n) {
+        int32_t i = n16 + l;
+        uint32_t prev = i ? src[i - 1] : 0u, c = src[i];
+        uint32_t row = DENSE ? (uint32_t)dmap[prev] : prev, col = DENSE ? (uint32_t)dmap[c] : c;
+        atomicAdd(&my[row * stride + col], 1u);
+    }
+    if (l == 0) {  // L170-173: the three quarter-start symbols are also counted in context 0
+        const int32_t q = n >> 2;
+        for (int k = 1; k < 4; k++) {
+            uint32_t c = src[k * q];
+            atomicAdd(&my[DENSE ? (uint32_t)dmap[c] : c], 1u);
+        }
+    }
+    __syncthreads();
+    if (R > 1) {
+        for (int j = l; j < cells; j += 64) {
+            uint32_t s = 0;
+            for (int r = 0; r < R; r++) s += rep[r * rstride + j];
+            cnt[j] += s;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// phase 2: normalisation, table serialisation, encoder symbols (one table row per lane)
+// ---------------------------------------------------------------------------------------------------------
+// Frequencies#writeFrequencies_o0 L215-244 over one row in dense form (syml: dense index -> byte value).
+template <bool WRITE>
+__device__ int row_body(const uint32_t* c, int n, const uint8_t* syml, uint8_t* dst) {
+    int p = 0, rle = 0;
+#define PUT(v)                          \
+    do {                                \
+        if (WRITE) dst[p] = (uint8_t)(v); \
+        p++;                            \
+    } while (0)
+    for (int d = 0; d < n; d++) {
+        int32_t f = (int32_t)c[d];
+        if (f == 0) continue;
+        int v = syml[d];
+        if (rle != 0) {
+            rle--;
+        } else {
+            PUT(v);
+            if (v > 0 && d > 0 && syml[d - 1] == v - 1 && c[d - 1] != 0) {
+                int k = d + 1;
+                while (k < n && syml[k] == syml[k - 1] + 1 && c[k] != 0) k++;
+                rle = k - (d + 1);
+                PUT(rle);
+            }
+        }
+        if (f < 128) {
+            PUT(f);
+        } else {
+            PUT(128 | (f >> 8));
+            PUT(f & 0xff);
+        }
+    }
+    PUT(0);
+#undef PUT
+    return p;
+}
+
+// order-1: normalise rows (L175-193), serialise (writeFrequencies_o1 L269-328), build symbols (buildSyms_o1 L248-265).
+// Returns the table length; table bytes go to tabdst.
+__device__ int32_t tables_o1(uint32_t* cnt, uint2* ent, int nrows, int n, int stride, EncFixedLds* L, uint8_t* tabdst,
+                             const uint32_t* rcp_tab) {
+    const int l = lane_id();
+    const int rpl = (nrows + 63) >> 6;  // rows per lane, contiguous so a lane scan gives row order
+    // normalise
+    for (int k = 0; k < rpl; k++) {
+        int row = l * rpl + k;
+        if (row >= nrows) break;
+        uint32_t* c = cnt + row * stride;
+        uint32_t T = 0;
+        for (int j = 0; j < n; j++) T += c[j];
+        L->rowT[row] = T;
+        if (T == 0) continue;
+        const double p = 4096.0 / (double)(int32_t)T;
+        int32_t m = 0, M = 0, t2 = 0;
+        for (int j = 0; j < n; j++) {
+            int32_t v = (int32_t)c[j];
+            if (v == 0) continue;
+            if (m < v) {
+                m = v;
+                M = j;
+            }
+            int32_t f = (int32_t)((double)v * p);
+            if (f == 0) f = 1;
+            t2 += f;
+            c[j] = (uint32_t)f;
+        }
+        t2++;
+        c[M] = (uint32_t)((int32_t)c[M] + (RANS_TOTFREQ - t2));
+    }
+    __syncthreads();
+    // serialised length of each present row: context header (index byte, run byte) + body
+    uint32_t mylen = 0;
+    for (int k = 0; k < rpl; k++) {
+        int row = l * rpl + k;
+        if (row >= nrows) break;
+        uint32_t len = 0;
+        if (L->rowT[row] != 0) {
+            int v = L->syml[row];
+            bool link = v > 0 && row > 0 && L->syml[row - 1] == v - 1 && L->rowT[row - 1] != 0;
+            if (!link) {
+                len = 1;
+            } else {
+                int pv = v - 1;
+                bool plink = pv > 0 && row > 1 && L->syml[row - 2] == pv - 1 && L->rowT[row - 2] != 0;
+                len = plink ? 0 : 2;
+            }
+            len += (uint32_t)row_body<false>(cnt + row * stride, n, L->syml, nullptr);
+        }
+        L->rowoff[row] = len;
+        mylen += len;
+    }
+    uint32_t total;
+    uint32_t base = wave_excl_scan(mylen, total);
+    __syncthreads();
+    for (int k = 0; k < rpl; k++) {
+        int row = l * rpl + k;
+        if (row >= nrows) break;
+        uint32_t len = L->rowoff[row];
+        if (L->rowT[row] != 0) {
+            uint8_t* d = tabdst + base;
+            int v = L->syml[row];
+            bool link = v > 0 && row > 0 && L->syml[row - 1] == v - 1 && L->rowT[row - 1] != 0;
+            if (!link) {
+                *d++ = (uint8_t)v;
+            } else {
+                int pv = v - 1;
+                bool plink = pv > 0 && row > 1 && L->syml[row - 2] == pv - 1 && L->rowT[row - 2] != 0;
+                if (!plink) {
+                    int kk = row + 1;
+                    while (kk < nrows && L->syml[kk] == L->syml[kk - 1] + 1 && L->rowT[kk] != 0) kk++;
+                    *d++ = (uint8_t)v;
+                    *d++ = (uint8_t)(kk - (row + 1));
+                }
+            }
+            row_body<true>(cnt + row * stride, n, L->syml, d);
+        }
+        base += len;
+    }
+    if (l == 0) tabdst[total] = 0;
+    // encoder symbols
+    for (int k = 0; k < rpl; k++) {
+        int row = l * rpl + k;
+        if (row >= nrows) break;
+        if (L->rowT[row] == 0) continue;
+        const uint32_t* c = cnt + row * stride;
+        uint2* e = ent + row * stride;
+        uint32_t C = 0;
+        for (int j = 0; j < n; j++) {
+            int32_t f = (int32_t)c[j];
+            if (f == 0) continue;
+            e[j] = pack_symbol(f, C, rcp_tab);
+            C += (uint32_t)f;
+        }
+    }
+    __syncthreads();
+    return (int32_t)total + 1;
+}
+
+// order-0: Frequencies#calcFrequencies_o0 L109-145, #writeFrequencies_o0 L215-244, #buildSyms_o0 L197-211.
+// cnt[256] raw counts in, normalised out; ent[256].
+__device__ int32_t tables_o0(uint32_t* cnt, uint2* ent, int32_t n_in, EncFixedLds* L, uint8_t* tabdst,
+                             const uint32_t* rcp_tab) {
+    const int l = lane_id();
+    const unsigned long long tr =
+        ((unsigned long long)RANS_TOTFREQ << 31) / (unsigned long long)n_in + (unsigned long long)((1 << 30) / n_in);
+    uint32_t c4[4];
+    unsigned long long key = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int j = l * 4 + k;
+        c4[k] = cnt[j];
+        unsigned long long kk = ((unsigned long long)c4[k] << 9) | (unsigned long long)(511 - j);
+        if (c4[k] != 0 && kk > key) key = kk;
+    }
+    key = wave_max64(key);
+    const int M = 511 - (int)(key & 511ull);
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (c4[k] != 0) {
+            int32_t f = (int32_t)(((unsigned long long)c4[k] * tr) >> 31);
+            if (f == 0) f = 1;
+            c4[k] = (uint32_t)f;
+            s += (uint32_t)f;
+        }
+    }
+    const int32_t fsum = (int32_t)wave_sum(s) + 1;
+    uint32_t tot, pre;
+    {
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int j = l * 4 + k;
+            if (j == M) c4[k] = (uint32_t)((int32_t)c4[k] + (RANS_TOTFREQ - fsum));
+            cnt[j] = c4[k];
+            mine += c4[k];
+        }
+        pre = wave_excl_scan(mine, tot);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int j = l * 4 + k;
+        if (c4[k] != 0) ent[j] = pack_symbol((int32_t)c4[k], pre, rcp_tab);
+        pre += c4[k];
+    }
+    __syncthreads();
+    int32_t len = 0;
+    if (l == 0) len = row_body<true>(cnt, 256, L->syml, tabdst);
+    len = __shfl(len, 0);
+    __syncthreads();
+    return len;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// phase 3: the coding loop
+// ---------------------------------------------------------------------------------------------------------
+enum { MODE_O0 = 0, MODE_O1_LDS = 1, MODE_O1_GLOBAL = 2 };
+
+// Returns payload length (including the 16 state bytes) or a negative code.  Payload is written downwards from pend.
+template <int MODE>
+__device__ int32_t encode_stream(const uint8_t* src, int32_t n, const uint2* ent, int stride, EncFixedLds* L,
+                                 uint8_t* pend, int32_t room) {
+    const int l = lane_id();
+    const int t = l >> 2, j = 3 - (l & 3);
+    const int32_t q = n >> 2;
+    int32_t U, rem = 0;
+    if (MODE == MODE_O0) {
+        U = q + 1;  // step 0 is the n&3 tail (E04 L17-33), then q full steps
+    } else {
+        rem = n - 4 * q;  // state 3 codes the remainder alone first (E14 L27-31)
+        U = q + rem;
+    }
+    uint32_t x = RANS_BYTE_L;
+    int32_t run = 0;
+    const int32_t limit = room - 16;
+    for (int32_t ub = 0; ub < U; ub += kSteps) {
+        const int32_t u = ub + t;
+        bool act = u < U;
+        int32_t pos = 0;
+        uint32_t ctx = 0;
+        if (MODE == MODE_O0) {
+            pos = (n & ~3) - 4 * u + j;
+            act = act && pos < n;  // u == 0: only states j < (n&3)
+        } else {
+            int32_t k;
+            if (j == 3) {
+                k = U - 1 - u;
+                pos = 3 * q + k;
+            } else {
+                k = q - 1 - (u - rem);
+                pos = j * q + k;
+                act = act && u >= rem;
+            }
+            if (act && k > 0) ctx = src[pos - 1];  // k == 0: the quarter's first symbol is coded in context 0
+        }
+        uint4 A = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);  // identity step for inactive (step, state) pairs
+        uint2 B = make_uint2(0u, 0u);
+        if (act) {
+            const uint32_t sym = src[pos];
+            uint2 e;
+            if (MODE == MODE_O0)
+                e = ent[sym];
+            else if (MODE == MODE_O1_LDS)
+                e = ent[(uint32_t)L->dmap[ctx] * (uint32_t)stride + L->dmap[sym]];
+            else
+                e = ent[ctx * 256u + sym];
+            expand_symbol(e, A, B);
+        }
+        L->stageA[t * 4 + j] = A;
+        L->stageB[t * 4 + j] = B;
+        __syncthreads();
+        if (l < 4) {
+#pragma unroll
+            for (int tt = 0; tt < kSteps; tt++) {
+                const uint4 a = L->stageA[tt * 4 + l];
+                const uint2 b = L->stageB[tt * 4 + l];
+                L->xs[tt * 4 + l] = x;
+                // Encoding#RansEncPutSymbol L46-71
+                uint32_t sh = (x >= a.x ? 8u : 0u) + (x >= a.y ? 8u : 0u);
+                uint32_t xr = x >> sh;
+                uint32_t qq = __umulhi(xr, a.z) >> b.y;
+                x = xr + a.w + qq * b.x;
+            }
+        }
+        __syncthreads();
+        const uint32_t xv = L->xs[t * 4 + j];
+        const int nb = (xv >= A.x ? 1 : 0) + (xv >= A.y ? 1 : 0);
+        const unsigned long long m1 = __ballot(nb >= 1), m2 = __ballot(nb == 2);
+        const int32_t tot = __popcll(m1) + __popcll(m2);
+        if (run + tot > limit) return CRAMGPU_E_INSUFFICIENT;
+        const int32_t idx = run + (int32_t)(mbcnt(m1) + mbcnt(m2));
+        if (nb >= 1) pend[-1 - idx] = (uint8_t)xv;
+        if (nb == 2) pend[-2 - idx] = (uint8_t)(xv >> 8);
+        run += tot;
+    }
+    // E04 L49-53 / E14 L78-82: big-endian rans3..rans0, then Utils#reverse => stream starts LE rans0..rans3
+    if (l < 4) {
+        uint8_t* p = pend - run - 16 + 4 * l;
+        p[0] = (uint8_t)x;
+        p[1] = (uint8_t)(x >> 8);
+        p[2] = (uint8_t)(x >> 16);
+        p[3] = (uint8_t)(x >> 24);
+    }
+    return run + 16;
+}
+
+__device__ void encode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* gs) {
+    const int l = lane_id();
+    EncFixedLds* L = reinterpret_cast<EncFixedLds*>(smem);
+    uint8_t* tab = smem + sizeof(EncFixedLds);
+    const cramgpu_block d = a.desc[b];
+    const int32_t n = d.in_len;
+    int order = d.order;
+    const uint8_t* src = a.in + d.in_off;
+    uint8_t* slot = a.out + d.out_off;
+    const int32_t cap = d.out_cap;
+    int32_t result;
+    int64_t pos = d.out_off;
+    if (order != 0 && order != 1) {
+        result = CRAMGPU_E_ORDER;
+    } else if (n == 0) {
+        result = 0;  // RANS#compress L61-62: EMPTY_BUFFER
+    } else if (n < 0 || cap < 9 + 2 + 16) {
+        result = n < 0 ? CRAMGPU_E_ARG : CRAMGPU_E_INSUFFICIENT;
+    } else {
+        if (n < 4) order = 0;  // RANS#compress L63-64
+        uint8_t* tabdst = slot + 9;
+        uint8_t* pend = slot + cap;
+        int32_t tab_len, pay_len;
+        uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);              // 256 words
+        uint2* ent0 = reinterpret_cast<uint2*>(tab + 1024);            // 256 x 8 B
+        uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
+        int R0 = 1;
+        while (R0 < 16 && (1024 + 2048 + 2 * R0 * 1024) <= a.tab_bytes) R0 <<= 1;
+        hist_o0(src, n, cnt0, rep0, R0);
+        if (order == 0) {
+            for (int i = l; i < 256; i += 64) L->syml[i] = (uint8_t)i;
+            __syncthreads();
+            tab_len = tables_o0(cnt0, ent0, n, L, tabdst, a.rcp_tab);
+            if (9 + tab_len + 16 > cap)
+                pay_len = CRAMGPU_E_INSUFFICIENT;
+            else
+                pay_len = encode_stream<MODE_O0>(src, n, ent0, 256, L, pend, cap - 9 - tab_len);
+        } else {
+            // dense alphabet = present symbols plus 0 (context 0 always exists)
+            uint32_t present = 0, mine = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int jj = l * 4 + k;
+                bool p = cnt0[jj] != 0 || jj == 0;
+                present |= (p ? 1u : 0u) << k;
+                mine += p ? 1u : 0u;
+            }
+            uint32_t nsym;
+            uint32_t di = wave_excl_scan(mine, nsym);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int jj = l * 4 + k;
+                if (present & (1u << k)) {
+                    L->dmap[jj] = (uint8_t)di;
+                    L->syml[di] = (uint8_t)jj;
+                    di++;
+                } else {
+                    L->dmap[jj] = 0;
+                }
+            }
+            __syncthreads();
+            const int ns = (int)nsym;
+            const int stride = ns | 1;
+            const int cells = ns * stride;
+            if (12 * cells + 16 <= a.tab_bytes) {
+                uint32_t* cnt = reinterpret_cast<uint32_t*>(tab);
+                const int ent_off = (4 * cells + 15) & ~15;
+                uint2* ent = reinterpret_cast<uint2*>(tab + ent_off);
+                const int rep_off = ent_off + 8 * cells;
+                const int rstride = cells | 1;
+                int R = 1;
+                while (R < 32 && rep_off + 2 * R * rstride * 4 <= a.tab_bytes) R <<= 1;
+                uint32_t* rep = reinterpret_cast<uint32_t*>(tab + rep_off);
+                for (int i = l; i < cells; i += 64) cnt[i] = 0;
+                __syncthreads();
+                hist_o1<true>(src, n, cnt, stride, L->dmap, rep, R, rstride, cells);
+                tab_len = tables_o1(cnt, ent, ns, ns, stride, L, tabdst, a.rcp_tab);
+                if (9 + tab_len + 16 > cap)
+                    pay_len = CRAMGPU_E_INSUFFICIENT;
+                else
+                    pay_len = encode_stream<MODE_O1_LDS>(src, n, ent, stride, L, pend, cap - 9 - tab_len);
+            } else {
+                uint32_t* cnt = reinterpret_cast<uint32_t*>(gs);
+                uint2* ent = reinterpret_cast<uint2*>(gs + 256 * 1024);
+                uint4* z = reinterpret_cast<uint4*>(gs);
+                for (int i = l; i < 256 * 1024 / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
+                for (int i = l; i < 256; i += 64) L->syml[i] = (uint8_t)i;
+                __threadfence();
+                __syncthreads();
+                hist_o1<false>(src, n, cnt, 256, nullptr, nullptr, 1, 0, 0);
+                __threadfence();
+                __syncthreads();
+                tab_len = tables_o1(cnt, ent, 256, 256, 256, L, tabdst, a.rcp_tab);
+                __threadfence();
+                __syncthreads();
+                if (9 + tab_len + 16 > cap)
+                    pay_len = CRAMGPU_E_INSUFFICIENT;
+                else
+                    pay_len = encode_stream<MODE_O1_GLOBAL>(src, n, ent, 256, L, pend, cap - 9 - tab_len);
+            }
+        }
+        if (pay_len < 0) {
+            result = pay_len;
+        } else {
+            // move the table in front of the payload (dst >= src: copy from the top down), then the 9-byte header
+            __threadfence_block();
+            __syncthreads();
+            uint8_t* dst = pend - pay_len - tab_len;
+            if (dst != tabdst) {
+                for (int32_t hi = tab_len; hi > 0; hi -= 64) {
+                    int32_t k = hi - 1 - l;
+                    uint8_t v = 0;
+                    if (k >= 0) v = tabdst[k];
+                    __threadfence_block();
+                    __syncthreads();
+                    if (k >= 0) dst[k] = v;
+                    __threadfence_block();
+                    __syncthreads();
+                }
+            }
+            uint8_t* h = dst - 9;
+            const uint32_t comp = (uint32_t)(tab_len + pay_len);
+            if (l == 0) h[0] = (uint8_t)order;  // RANS#finalizeCompressed L132-142
+            if (l >= 1 && l < 5) h[l] = (uint8_t)(comp >> (8 * (l - 1)));
+            if (l >= 5 && l < 9) h[l] = (uint8_t)((uint32_t)n >> (8 * (l - 5)));
+            result = 9 + tab_len + pay_len;
+            pos = (int64_t)(h - a.out);
+        }
+    }
+    if (l == 0) {
+        a.out_len[b] = result;
+        a.out_pos[b] = pos;
+    }
+}
+
+__global__ __launch_bounds__(64) void rans_encode_kernel(RansArgs a) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint8_t* gs = a.gscratch + (size_t)blockIdx.x * ENC_GSCRATCH_BYTES;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(a.ticket, 1u);
+        t = __shfl(t, 0);
+        if (t >= (uint32_t)a.n_blocks) break;  // every wave reaches this: the queue only grows
+        encode_block(a, a.perm[t], smem, gs);
+        __syncthreads();
+    }
+}
+
+// Encoding#RansEncSymbolInit L31-36: rcp_freq = (int)(((1L << (shift + 31)) + freq - 1) / freq) for freq >= 2
+__global__ void rcp_init_kernel(uint32_t* tab) {
+    uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= 4096) return;
+    uint32_t v = ~0u;
+    if (f >= 2) {
+        uint32_t shift = 0;
+        while ((unsigned long long)f > (1ull << shift)) shift++;
+        v = (uint32_t)(((1ull << (shift + 31)) + f - 1) / f);
+    }
+    tab[f] = v;
+}
+
+}  // namespace
+
+size_t rans_encode_fixed_lds() { return sizeof(EncFixedLds); }
+
+hipError_t launch_rans_encode(const RansArgs& a, int n_waves, size_t lds_bytes, hipStream_t s) {
+    hipLaunchKernelGGL(rans_encode_kernel, dim3(n_waves), dim3(64), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rcp_init(uint32_t* d_rcp_tab, hipStream_t s) {
+    hipLaunchKernelGGL(rcp_init_kernel, dim3(16), dim3(256), 0, s, d_rcp_tab);
+    return hipGetLastError();
+}

@@ -1,0 +1,639 @@
+// K3 / K4 / K5 — record-level kernels of the cramtools hot path over flat (structure-of-arrays) containers.
+//
+// Reference:
+//   F1/F2  htsjdk!build/Sam2CramRecordFactory#createVariations L205-264, #addSubstitutionsAndMaskedBases L297-335,
+//          #addInsertion L282-292, #addSoftClip L268-272, htsjdk!build/Utils#normalizeBase L31-49
+//   F3     htsjdk!build/CompressionHeaderFactory#buildFrequencies L196-209 (the 5x5 substitution histogram)
+//   N1     src/main/java/htsjdk/samtools/cram/build/CramNormalizer.java:335-441 (restoreReadBases)
+//   N2     CramNormalizer.java:287-333 (restoreQualityScores)
+//   Q2     src/main/java/htsjdk/samtools/cram/lossy/QualityScorePreservation.java:258-301,332-489,
+//          lossy/Binning.java:63-71, ref/ReferenceTracks.java:127-155
+//
+// Mapping: one wavefront per read; the CIGAR / feature list of the read is walked by the whole wave (uniform
+// control flow) and the 64 lanes sweep the bases of each element with coalesced byte loads of the read and of the
+// reference window.  Mismatches are compacted with a wave ballot + mbcnt prefix so that features leave in the
+// reference's order (CIGAR order, ascending position).  Feature extraction runs twice (count, exclusive scan,
+// write) because the feature arrays are dense across reads.
+#include "internal.h"
+
+namespace {
+
+enum { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP_P = 6, OP_EQ = 7, OP_X = 8 };
+
+__device__ __forceinline__ uint32_t mbcnt(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// htsjdk!build/Utils#normalizeBase L31-49: acgtACGT -> upper case, everything else -> 'N'
+__device__ __forceinline__ uint8_t normalize_base(uint8_t b) {
+    const uint8_t lo = b | 0x20;
+    return (lo == 'a' || lo == 'c' || lo == 'g' || lo == 't') ? (uint8_t)(b & 0xDF) : (uint8_t)'N';
+}
+__device__ __forceinline__ int acgtn_index(uint8_t b) {
+    return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : b == 'N' ? 4 : -1;
+}
+__device__ __forceinline__ bool consumes_read(int op) {
+    return op == OP_M || op == OP_I || op == OP_S || op == OP_EQ || op == OP_X;
+}
+__device__ __forceinline__ bool consumes_ref(int op) {
+    return op == OP_M || op == OP_D || op == OP_N || op == OP_EQ || op == OP_X;
+}
+__device__ __forceinline__ int wave_index() { return (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); }
+__device__ __forceinline__ int wave_count() { return (int)((gridDim.x * blockDim.x) >> 6); }
+
+// ------------------------------------------------------------------------------------------------------
+// K3: feature extraction.  WRITE=false: counts[r] = number of features of read r.  WRITE=true: emit at off[r].
+// ------------------------------------------------------------------------------------------------------
+template <bool WRITE>
+__global__ __launch_bounds__(256) void extract_kernel(cramgpu_reads R, const uint8_t* ref, cramgpu_features F,
+                                                      int64_t* sub_hist, int32_t* counts) {
+    const int lane = threadIdx.x & 63;
+    const int n_waves = wave_count();
+    for (int r = wave_index(); r < R.n_reads; r += n_waves) {
+        const uint8_t fl = R.rflags[r];
+        const int32_t start = R.aln_start[r];
+        const int cont = R.read_cont ? R.read_cont[r] : 0;
+        int64_t nf = 0;
+        const int64_t o = WRITE ? F.off[r] : 0;
+        if (!(fl & (CRAMGPU_RF_UNMAPPED | CRAMGPU_RF_SKIP)) && start != 0) {
+            const cramgpu_refwin W = R.win[cont];
+            const uint8_t* wref = ref + W.ref_off;
+            const uint8_t* rb = R.bases + R.base_off[r];
+            const bool nobases = (fl & CRAMGPU_RF_NO_BASES) != 0;
+            const int nc = R.n_cigar[r];
+            const uint32_t* cg = R.cigar + R.cigar_off[r];
+            int pos = 0, refoff = 0;
+            for (int k = 0; k < nc; k++) {
+                const uint32_t ce = cg[k];
+                const int op = (int)(ce & 15u), len = (int)(ce >> 4);
+                if (op == OP_D || op == OP_N || op == OP_P || op == OP_H || op == OP_S) {
+                    if (WRITE && lane == 0) {
+                        const int64_t i = o + nf;
+                        F.op[i] = op == OP_D ? 'D' : op == OP_N ? 'N' : op == OP_P ? 'P' : op == OP_H ? 'H' : 'S';
+                        F.pos[i] = pos + 1;
+                        F.a[i] = op == OP_S ? pos : len;
+                        F.b[i] = op == OP_S ? len : 0;
+                    }
+                    nf += 1;
+                } else if (op == OP_I) {
+                    if (WRITE) {
+                        for (int i = lane; i < len; i += 64) {
+                            const int64_t x = o + nf + i;
+                            F.op[x] = 'i';
+                            F.pos[x] = pos + 1 + i;
+                            F.a[x] = nobases ? 'N' : rb[pos + i];
+                            F.b[x] = 0;
+                        }
+                    }
+                    nf += len;
+                } else if (op == OP_M || op == OP_EQ || op == OP_X) {
+                    for (int i0 = 0; i0 < len; i0 += 64) {
+                        const int i = i0 + lane;
+                        bool mis = false;
+                        uint8_t b = 0, refb = 0;
+                        if (i < len) {
+                            const int64_t rc = (int64_t)start + i + refoff - 1 - W.ref_start0;
+                            refb = (rc < 0 || rc >= W.ref_len) ? (uint8_t)'N' : wref[rc];
+                            refb = normalize_base(refb);
+                            b = nobases ? (uint8_t)'N' : rb[pos + i];
+                            mis = b != refb;
+                        }
+                        const unsigned long long m = __ballot(mis);
+                        if (WRITE && m) {
+                            int key = -1;
+                            if (mis) {
+                                const int64_t x = o + nf + mbcnt(m);
+                                F.op[x] = 'X';
+                                F.pos[x] = pos + i + 1;
+                                F.a[x] = (int32_t)b | ((int32_t)refb << 8) | (0xFF << 16);
+                                F.b[x] = 0;
+                                const int bi = acgtn_index(b);
+                                if (bi >= 0) key = acgtn_index(refb) * 5 + bi;
+                            }
+                            if (sub_hist) {
+                                // one atomic per distinct (ref, base) pair of the wave
+                                unsigned long long todo = __ballot(key >= 0);
+                                while (todo) {
+                                    const int leader = __ffsll((long long)todo) - 1;
+                                    const int k0 = __shfl(key, leader);
+                                    const unsigned long long same = __ballot(key == k0);
+                                    if (lane == leader)
+                                        atomicAdd((unsigned long long*)&sub_hist[(int64_t)cont * 25 + k0],
+                                                  (unsigned long long)__popcll(same));
+                                    todo &= ~same;
+                                }
+                            }
+                        }
+                        nf += __popcll(m);
+                    }
+                }
+                if (consumes_read(op)) pos += len;
+                if (consumes_ref(op)) refoff += len;
+            }
+        }
+        if (!WRITE && lane == 0) counts[r] = (int32_t)nf;
+    }
+}
+
+// exclusive scan of int32 counts into int64 offsets (off[n] = total), single workgroup
+__global__ __launch_bounds__(1024) void scan_kernel(const int32_t* counts, int32_t n, int64_t* off, int64_t* total) {
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(n, t * per), hi = min(n, lo + per);
+    int64_t s = 0;
+    for (int i = lo; i < hi; i++) s += counts[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int64_t v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int64_t base = part[t] - s;
+    for (int i = lo; i < hi; i++) {
+        off[i] = base;
+        base += counts[i];
+    }
+    if (t == 1023) {
+        off[n] = part[1023];
+        if (total) *total = part[1023];
+    }
+}
+
+// htsjdk!encoding/writer/Writer#write L139-261 -> SubstitutionMatrix#code: codes[cont][ref 5][base 256]
+__global__ void assign_codes_kernel(int32_t n_reads, const int32_t* read_cont, const int64_t* off, const uint8_t* op,
+                                    int32_t* a, const uint8_t* codes) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint8_t* cd = codes + (size_t)(read_cont ? read_cont[r] : 0) * 5 * 256;
+    for (int64_t f = off[r]; f < off[r + 1]; f++) {
+        if (op[f] != 'X') continue;
+        const int32_t v = a[f];
+        const int ri = acgtn_index((uint8_t)(v >> 8));
+        const int code = ri >= 0 ? cd[ri * 256 + (v & 0xff)] : 0;
+        a[f] = (v & 0xffff) | (code << 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K4 / N1: CramNormalizer.restoreReadBases.  basesof[cont][ref 5][code 4].
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void restore_bases_kernel(int32_t n_reads, const int32_t* read_len,
+                                                            const int32_t* aln_start, const uint8_t* rflags,
+                                                            const int32_t* read_cont, const cramgpu_refwin* wins,
+                                                            cramgpu_features F, const uint8_t* seq, const int64_t* seq_off,
+                                                            const uint8_t* ref, const uint8_t* basesof, uint8_t* out,
+                                                            const int64_t* out_off, int32_t* status) {
+    const int lane = threadIdx.x & 63;
+    const int n_waves = wave_count();
+    for (int r = wave_index(); r < n_reads; r += n_waves) {
+        const uint8_t fl = rflags[r];
+        const int L = read_len[r];
+        int st = 0;
+        if (fl & CRAMGPU_RF_SKIP) {
+            st = 2;
+        } else if ((fl & CRAMGPU_RF_UNKNOWN_BASES) || L == 0) {
+            st = 1;  // :336-337 NULL_SEQUENCE
+        } else {
+            const int cont = read_cont ? read_cont[r] : 0;
+            const cramgpu_refwin W = wins[cont];
+            const uint8_t* win = ref + W.ref_off;
+            const int64_t wlen = W.ref_len, ws0 = W.ref_start0;
+            const uint8_t* bo = basesof + (size_t)cont * 20;
+            uint8_t* b = out + out_off[r];
+            const int64_t al0 = (int64_t)aln_start[r] - 1;
+            const int64_t fb = F.off[r], fe = F.off[r + 1];
+            if (fb == fe) {
+                // :343-364 no features: plain copy, 'N' beyond the window, no normalisation
+                if (wlen + ws0 < al0 + L) {
+                    const int64_t off = al0 - ws0, avail = wlen - off;
+                    const int64_t ncopy = (off > 0 && avail > 0) ? (L < avail ? L : avail) : 0;
+                    for (int i = lane; i < L; i += 64) b[i] = i < ncopy ? win[off + i] : (uint8_t)'N';
+                } else if (al0 - ws0 < 0) {
+                    st = CRAMGPU_E_JAVA_THROWS;
+                } else {
+                    const uint8_t* s = win + (al0 - ws0);
+                    for (int i = lane; i < L; i += 64) b[i] = s[i];
+                }
+            } else {
+                int pir = 1;      // posInRead (1-based)
+                int64_t pis = 0;  // posInSeq
+                bool bad = false;
+                for (int64_t f = fb; f < fe && !bad; f++) {
+                    const int fpos = F.pos[f];
+                    const int opc = F.op[f];
+                    const int32_t fa = F.a[f], fbv = F.b[f];
+                    const int gap = fpos - pir;
+                    if (gap > 0) {  // :368-370 copy reference up to the feature
+                        if (al0 + pis - ws0 < 0 || pir - 1 + gap > L) {
+                            bad = true;
+                            break;
+                        }
+                        for (int i = lane; i < gap; i += 64) {
+                            const int64_t rp = al0 + pis + i - ws0;
+                            b[pir - 1 + i] = normalize_base(rp >= wlen ? (uint8_t)'N' : win[rp]);
+                        }
+                        pir += gap;
+                        pis += gap;
+                    }
+                    if (opc == 'X') {
+                        const int64_t rp = al0 + pis - ws0;
+                        if (rp < 0 || pir - 1 >= L) {
+                            bad = true;
+                            break;
+                        }
+                        if (lane == 0) {
+                            const uint8_t rbase = normalize_base(rp >= wlen ? (uint8_t)'N' : win[rp]);
+                            b[pir - 1] = normalize_base(bo[acgtn_index(rbase) * 4 + ((fa >> 16) & 3)]);
+                        }
+                        pir++;
+                        pis++;
+                    } else if (opc == 'I' || opc == 'S') {
+                        if (fbv < 0 || pir - 1 + fbv > L) {
+                            bad = true;
+                            break;
+                        }
+                        const uint8_t* s = seq + seq_off[r] + fa;
+                        for (int i = lane; i < fbv; i += 64) b[pir - 1 + i] = normalize_base(s[i]);
+                        pir += fbv;
+                    } else if (opc == 'D' || opc == 'N') {
+                        pis += fa;
+                    } else if (opc == 'i') {
+                        if (pir - 1 >= L) {
+                            bad = true;
+                            break;
+                        }
+                        if (lane == 0) b[pir - 1] = normalize_base((uint8_t)fa);
+                        pir++;
+                    }
+                }
+                if (!bad) {
+                    // :412-415 tail from the reference while it lasts, then the never-written rest reads as 0 -> 'N'
+                    const int64_t rp0 = al0 + pis - ws0;
+                    int64_t ncopy = (int64_t)L - (pir - 1);
+                    if (wlen - rp0 < ncopy) ncopy = wlen - rp0;
+                    if (ncopy < 0) ncopy = 0;
+                    if (ncopy > 0 && rp0 < 0) {
+                        bad = true;
+                    } else {
+                        for (int i = lane; i < L - (pir - 1); i += 64)
+                            b[pir - 1 + i] = i < ncopy ? normalize_base(win[rp0 + i]) : (uint8_t)'N';
+                        // :418-427 ReadBase features overwrite
+                        __threadfence_block();
+                        __builtin_amdgcn_wave_barrier();
+                        for (int64_t f = fb + lane; f < fe; f += 64) {
+                            if (F.op[f] == 'B') {
+                                const int p = F.pos[f];
+                                if (p < 1 || p > L)
+                                    bad = true;
+                                else
+                                    b[p - 1] = normalize_base((uint8_t)F.a[f]);
+                            }
+                        }
+                        bad = __ballot(bad) != 0;
+                    }
+                }
+                if (bad) st = CRAMGPU_E_JAVA_THROWS;
+            }
+        }
+        if (lane == 0) status[r] = st;
+    }
+}
+
+// N2: CramNormalizer.restoreQualityScores :287-333
+__global__ __launch_bounds__(256) void restore_quals_kernel(int32_t n_reads, const int32_t* read_len, const uint8_t* rflags,
+                                                            cramgpu_features F, uint8_t default_qs, uint8_t* scores,
+                                                            const int64_t* out_off, int32_t* status) {
+    const int lane = threadIdx.x & 63;
+    const int n_waves = wave_count();
+    for (int r = wave_index(); r < n_reads; r += n_waves) {
+        const uint8_t fl = rflags[r];
+        const int L = read_len[r];
+        int st;
+        if (fl & CRAMGPU_RF_SKIP) {
+            st = 2;
+        } else {
+            uint8_t* s = scores + out_off[r];
+            if (!(fl & CRAMGPU_RF_FORCE_QS)) {
+                for (int i = lane; i < L; i += 64) s[i] = default_qs;
+                __threadfence_block();
+                __builtin_amdgcn_wave_barrier();
+                bool any = false;
+                for (int64_t f = F.off[r] + lane; f < F.off[r + 1]; f += 64) {
+                    const int opc = F.op[f];
+                    if (opc == 'Q') {
+                        s[F.pos[f] - 1] = (uint8_t)F.a[f];
+                        any = true;
+                    } else if (opc == 'B') {
+                        s[F.pos[f] - 1] = (uint8_t)F.b[f];
+                        any = true;
+                    }
+                }
+                st = __ballot(any) ? 0 : 1;
+            } else {
+                int missing = 0;
+                for (int i = lane; i < L; i += 64) {
+                    if (s[i] == 0xFF) {
+                        s[i] = default_qs;
+                        missing++;
+                    }
+                }
+                for (int o = 32; o > 0; o >>= 1) missing += __shfl_xor(missing, o);
+                st = missing == L ? 1 : 0;
+            }
+        }
+        if (lane == 0) status[r] = st;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K5 / Q2: QualityScorePreservation.addQualityScores (one wave per read; mask in LDS, global scratch for long reads)
+// ------------------------------------------------------------------------------------------------------
+__constant__ uint8_t kIllumina8[110] = {  // lossy/Binning.java:63-71
+    0,  1,  6,  6,  6,  6,  6,  6,  6,  6,  15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 22, 22, 22, 22, 22, 27, 27, 27,
+    27, 27, 33, 33, 33, 33, 33, 37, 37, 37, 37, 37, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40,
+    40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40,
+    40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40};
+
+constexpr int kMaskLds = 16384;
+
+__device__ __forceinline__ bool read_gate(const cramgpu_policy& p, bool unmapped, int mapq) {
+    switch (p.read_cat) {
+        case 0: case 4: return true;
+        case 1: return unmapped;
+        case 3: return mapq < p.read_param;
+        case 2: return mapq > p.read_param;
+        default: return false;
+    }
+}
+
+__global__ __launch_bounds__(64) void lossy_quals_kernel(cramgpu_reads R, const uint8_t* ref, const int32_t* wpos,
+                                                         int32_t window, const cramgpu_policy* pol, int32_t n_pol,
+                                                         uint8_t* scores, uint8_t* force, int32_t* status,
+                                                         uint8_t* mask_ws) {
+    __shared__ uint8_t lmask[kMaskLds];
+    const int lane = threadIdx.x;
+    for (int r = blockIdx.x; r < R.n_reads; r += gridDim.x) {
+        const uint8_t fl = R.rflags[r];
+        int st = 0;
+        int frc = 0;
+        if (fl & CRAMGPU_RF_SKIP) {
+            st = 2;
+        } else if (fl & CRAMGPU_RF_NULL_QUALS) {
+            st = 1;  // :277-281
+        } else {
+            const int L = R.read_len[r];
+            const int64_t bo = R.base_off[r];
+            const uint8_t* qs = R.quals + bo;
+            const uint8_t* rb = R.bases + bo;
+            uint8_t* sc = scores + bo;
+            uint8_t* mask = (L + 1 <= kMaskLds) ? lmask : (mask_ws + bo + r);
+            const int cont = R.read_cont ? R.read_cont[r] : 0;
+            const cramgpu_refwin W = R.win[cont];
+            const uint8_t* wref = ref + W.ref_off;
+            const int64_t contig_len = W.ref_start0 + W.ref_len;
+            const int64_t Wn = window < contig_len ? window : contig_len;
+            const int32_t start = R.aln_start[r];
+            const bool unmapped = (fl & CRAMGPU_RF_UNMAPPED) != 0;
+            const int mapq = R.mapq[r];
+            const int nc = R.n_cigar[r];
+            const uint32_t* cg = R.cigar + R.cigar_off[r];
+            const int64_t wp = wpos[r];
+            bool bad = false;
+            for (int i = lane; i < L; i += 64) sc[i] = 0xFF;
+            __threadfence_block();
+            __syncthreads();
+            for (int k = 0; k < n_pol && !bad; k++) {
+                const cramgpu_policy p = pol[k];
+                if (!read_gate(p, unmapped, mapq)) continue;
+                if (p.n_base_cat == 0) {  // :362-388 whole-read treatment
+                    if (p.treatment == 1) {
+                        for (int i = lane; i < L; i += 64) {
+                            const uint8_t q = qs[i];
+                            if (q >= 110)
+                                bad = true;
+                            else
+                                sc[i] = kIllumina8[q];
+                        }
+                        frc = 1;
+                    } else if (p.treatment == 0) {
+                        for (int i = lane; i < L; i += 64) sc[i] = qs[i];
+                        frc = 1;
+                    } else {
+                        frc = 0;
+                    }
+                    bad = __ballot(bad) != 0;
+                    continue;
+                }
+                if (start == 0) continue;  // :394-396
+                for (int i = lane; i < L + 1; i += 64) mask[i] = 0;
+                __threadfence_block();
+                __syncthreads();
+                for (int c = 0; c < p.n_base_cat && !bad; c++) {
+                    const int type = p.base_cat[c];
+                    int pos = 0;
+                    int64_t refpos = start;
+                    if (type == 4) {  // PILEUP against all-zero tracks: mismatchesAt() == 0
+                        if (0 > p.base_param[c])
+                            for (int i = lane; i < L; i += 64) mask[i] = 1;
+                    } else {
+                        for (int e = 0; e < nc && !bad; e++) {
+                            const uint32_t ce = cg[e];
+                            const int op = (int)(ce & 15u), len = (int)(ce >> 4);
+                            if (type == 3) {
+                                if (op == OP_D) {
+                                    if (pos >= L) {
+                                        bad = true;
+                                    } else if (lane == 0) {
+                                        mask[pos] = 1;
+                                        if (pos + 1 < L) mask[pos + 1] = 1;
+                                    }
+                                }
+                            } else if (type == 1 || type == 2) {
+                                if (consumes_read(op)) {
+                                    if (pos + len > L || refpos - wp < 0) {
+                                        bad = len > 0;
+                                    } else {
+                                        for (int i = lane; i < len; i += 64) {
+                                            const int64_t rp = refpos + i;
+                                            const int64_t gi = rp - 1 - W.ref_start0;
+                                            const uint8_t tb = (rp - wp < Wn && gi >= 0 && gi < W.ref_len) ? wref[gi] : (uint8_t)'N';
+                                            const bool match = rb[pos + i] == tb;
+                                            mask[pos + i] = (type == 1 && match) || (type == 2 && !match);
+                                        }
+                                    }
+                                }
+                            } else if (type == 6) {
+                                if (op == OP_I) {
+                                    if (pos + len > L)
+                                        bad = len > 0;
+                                    else
+                                        for (int i = lane; i < len; i += 64) mask[pos + i] = 1;
+                                }
+                            } else if (type == 5) {  // LOWER_COVERAGE against all-zero tracks: coverageAt() == 0
+                                if (op == OP_M || op == OP_EQ || op == OP_X) {
+                                    if (pos + len > L)
+                                        bad = len > 0;
+                                    else
+                                        for (int i = lane; i < len; i += 64) mask[pos + i] = 0 < p.base_param[c];
+                                }
+                            }
+                            if (consumes_read(op)) pos += len;
+                            if (consumes_ref(op)) refpos += len;
+                            if (type == 3) {  // lane 0's two writes must land before a later category overwrites them
+                                __threadfence_block();
+                                __syncthreads();
+                            }
+                        }
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                }
+                if (bad) break;
+                int masked = 0;
+                for (int i = lane; i < L; i += 64) {
+                    if (mask[i]) {
+                        const uint8_t q = qs[i];
+                        if (p.treatment == 1) {
+                            if (q >= 110)
+                                bad = true;
+                            else
+                                sc[i] = kIllumina8[q];
+                        } else if (p.treatment == 2) {
+                            sc[i] = 0xFF;
+                        } else {
+                            sc[i] = q;
+                        }
+                        masked++;
+                    }
+                }
+                for (int o = 32; o > 0; o >>= 1) masked += __shfl_xor(masked, o);
+                bad = __ballot(bad) != 0;
+                if (masked > L / 2) frc = 1;  // :486-488 safety latch
+                __threadfence_block();
+                __syncthreads();
+            }
+            if (bad) st = CRAMGPU_E_JAVA_THROWS;
+        }
+        if (lane == 0) {
+            force[r] = (uint8_t)frc;
+            status[r] = st;
+        }
+        __syncthreads();
+    }
+}
+
+// Tail of addQualityScores :288-299.  WRITE=false: counts[r] = merged feature count.  One thread per read.
+template <bool WRITE>
+__global__ void merge_quality_kernel(int32_t n_reads, const int32_t* read_len, const int64_t* base_off,
+                                     const uint8_t* scores, const uint8_t* force, const int32_t* qstatus,
+                                     cramgpu_features in, cramgpu_features out, int32_t* counts) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int64_t f = in.off[r];
+    const int64_t fe = in.off[r + 1];
+    const bool addq = qstatus[r] == 0 && !force[r];
+    const int L = read_len[r];
+    const uint8_t* sc = scores + base_off[r];
+    int64_t n = WRITE ? out.off[r] : 0;
+    const int64_t n0 = n;
+#define COPYF()                     \
+    do {                            \
+        if (WRITE) {                \
+            out.op[n] = in.op[f];   \
+            out.pos[n] = in.pos[f]; \
+            out.a[n] = in.a[f];     \
+            out.b[n] = in.b[f];     \
+        }                           \
+        n++;                        \
+        f++;                        \
+    } while (0)
+    if (addq) {
+        for (int i = 0; i < L; i++) {
+            const uint8_t s = sc[i];
+            if (s >= 128) continue;  // scores[i] > -1 as a signed byte
+            while (f < fe && in.pos[f] <= i + 1) COPYF();
+            if (WRITE) {
+                out.op[n] = 'Q';
+                out.pos[n] = i + 1;
+                out.a[n] = s;
+                out.b[n] = 0;
+            }
+            n++;
+        }
+    }
+    while (f < fe) COPYF();
+#undef COPYF
+    if (!WRITE) counts[r] = (int32_t)(n - n0);
+}
+
+}  // namespace
+
+static int grid_for_waves(int64_t n_items, int waves_per_block) {
+    int64_t blocks = (n_items + waves_per_block - 1) / waves_per_block;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    return (int)blocks;
+}
+
+hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
+                                   int32_t* d_counts, bool write_pass, hipStream_t s) {
+    const int grid = grid_for_waves(r.n_reads, 4);
+    if (write_pass)
+        hipLaunchKernelGGL(extract_kernel<true>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts);
+    else
+        hipLaunchKernelGGL(extract_kernel<false>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_feature_scan(int32_t n_reads, const int32_t* d_counts, int64_t* d_off, int64_t* d_total, hipStream_t s) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, d_counts, n_reads, d_off, d_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_assign_codes(int32_t n_reads, const int32_t* read_cont, const int64_t* off, const uint8_t* op,
+                               int32_t* a, const uint8_t* d_codes, hipStream_t s) {
+    hipLaunchKernelGGL(assign_codes_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, s, n_reads, read_cont, off, op, a,
+                       d_codes);
+    return hipGetLastError();
+}
+
+hipError_t launch_restore_bases(int32_t n_reads, const int32_t* read_len, const int32_t* aln_start, const uint8_t* rflags,
+                                const int32_t* read_cont, const cramgpu_refwin* wins, cramgpu_features f,
+                                const uint8_t* seq, const int64_t* seq_off, const uint8_t* ref, const uint8_t* d_basesof,
+                                uint8_t* out, const int64_t* out_off, int32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(restore_bases_kernel, dim3(grid_for_waves(n_reads, 4)), dim3(256), 0, s, n_reads, read_len,
+                       aln_start, rflags, read_cont, wins, f, seq, seq_off, ref, d_basesof, out, out_off, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_restore_quals(int32_t n_reads, const int32_t* read_len, const uint8_t* rflags, cramgpu_features f,
+                                uint8_t default_qs, uint8_t* scores, const int64_t* out_off, int32_t* status,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(restore_quals_kernel, dim3(grid_for_waves(n_reads, 4)), dim3(256), 0, s, n_reads, read_len, rflags,
+                       f, default_qs, scores, out_off, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_lossy_quals(const cramgpu_reads& r, const uint8_t* ref, const int32_t* wpos, int32_t window,
+                              const cramgpu_policy* d_pol, int32_t n_pol, uint8_t* scores, uint8_t* force,
+                              int32_t* status, uint8_t* d_mask_ws, hipStream_t s) {
+    int grid = r.n_reads < 256 * 8 ? (r.n_reads > 0 ? r.n_reads : 1) : 256 * 8;
+    hipLaunchKernelGGL(lossy_quals_kernel, dim3(grid), dim3(64), 0, s, r, ref, wpos, window, d_pol, n_pol, scores, force,
+                       status, d_mask_ws);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_quality(int32_t n_reads, const int32_t* read_len, const int64_t* base_off, const uint8_t* scores,
+                                const uint8_t* force, const int32_t* qstatus, cramgpu_features in, cramgpu_features out,
+                                int32_t* d_counts, bool write_pass, hipStream_t s) {
+    const int grid = (n_reads + 255) / 256;
+    if (write_pass)
+        hipLaunchKernelGGL(merge_quality_kernel<true>, dim3(grid), dim3(256), 0, s, n_reads, read_len, base_off, scores,
+                           force, qstatus, in, out, d_counts);
+    else
+        hipLaunchKernelGGL(merge_quality_kernel<false>, dim3(grid), dim3(256), 0, s, n_reads, read_len, base_off, scores,
+                           force, qstatus, in, out, d_counts);
+    return hipGetLastError();
+}

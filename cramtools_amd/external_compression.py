@@ -1,0 +1,189 @@
+"""Host-side mirror of the reference's block-codec plugin interface, backed by libcramgpu (HIP, gfx950 only).
+
+Reference interface (SURVEY.md §8(b) level 0/1):
+  htsjdk!io/ExternalCompression#rans(byte[], int|ORDER) L89-90,101-102   -> rans(data, order)
+  htsjdk!io/ExternalCompression#unrans(byte[]) L112-113                  -> unrans(data)
+  htsjdk!encoding/ExternalCompressor#createRANS(ORDER) L76, $5#compress  -> ExternalCompressor.createRANS(order).compress
+  htsjdk!structure/BlockCompressionMethod                                -> ExternalCompressor.getMethod() == 4 (RANS)
+Same argument meaning and error behaviour: empty in -> empty out, < 4 bytes -> order 0, errors raise RuntimeError
+subclasses carrying the reference's messages.  `Engine` is the batch (whole-container) form over device arenas.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Block, CramGpuError
+
+ORDER_ZERO, ORDER_ONE = 0, 1
+RANS_METHOD = 4  # BlockCompressionMethod.RANS ordinal
+
+
+def rans_bound(n):
+    return int(_lib.lib().cramgpu_rans_bound(int(n)))
+
+
+def rans(data, order):
+    """ExternalCompression.rans(byte[] data, int order) -> bytes."""
+    if order not in (0, 1):
+        raise CramGpuError(_lib.E_ORDER, "Unknown rANS order: %r" % (order,))
+    d = np.frombuffer(bytes(data), np.uint8)
+    if d.size == 0:
+        return b""
+    cap = rans_bound(d.size)
+    out = np.empty(cap, np.uint8)
+    r = _lib.lib().cramgpu_rans_compress(d.ctypes.data, d.size, order, out.ctypes.data, cap)
+    _lib.check(r)
+    return out[:r].tobytes()  # ExternalCompression#toByteArray L146-150: exact-size copy
+
+
+def unrans(data):
+    """ExternalCompression.unrans(byte[] data) -> bytes."""
+    d = np.frombuffer(bytes(data), np.uint8)
+    if d.size == 0:
+        return b""
+    raw = _lib.check(_lib.lib().cramgpu_rans_raw_size(d.ctypes.data, d.size))
+    out = np.empty(max(raw, 1), np.uint8)
+    r = _lib.check(_lib.lib().cramgpu_rans_uncompress(d.ctypes.data, d.size, out.ctypes.data, raw))
+    return out[:r].tobytes()
+
+
+class ExternalCompressor:
+    """htsjdk!encoding/ExternalCompressor: the per-data-series plugin object (rANS flavours only)."""
+
+    def __init__(self, order):
+        self.order = order
+
+    @staticmethod
+    def createRANS(order):
+        return ExternalCompressor(order)
+
+    def getMethod(self):
+        return RANS_METHOD
+
+    def compress(self, data):
+        return rans(data, self.order)
+
+
+def _align(v, a=_lib.ARENA_ALIGN):
+    return (int(v) + a - 1) // a * a
+
+
+class Engine:
+    """One context (= one GPU).  Batch encode/decode over device arenas held as torch uint8 tensors."""
+
+    def __init__(self, device_index=0):
+        self._h = _lib.lib().cramgpu_open(int(device_index))
+        if not self._h:
+            raise CramGpuError(_lib.E_NO_DEVICE, _lib.last_error())
+        self.device_index = int(device_index)
+
+    def close(self):
+        if self._h:
+            _lib.lib().cramgpu_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        a, b = C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().cramgpu_info(self._h, C.byref(a), C.byref(b)))
+        return {"n_cu": a.value, "n_waves": b.value}
+
+    # ---- layout helpers (host) ----
+    @staticmethod
+    def plan_encode(lengths, orders):
+        """Descriptor table for raw blocks packed back to back (16-byte aligned) -> (Block array, in_bytes, out_bytes)."""
+        n = len(lengths)
+        blocks = (Block * max(n, 1))()
+        io = oo = 0
+        for i in range(n):
+            ln = int(lengths[i])
+            cap = rans_bound(ln)
+            blocks[i] = Block(io, oo, ln, cap, int(orders[i]), 0)
+            io += _align(ln)
+            oo += _align(cap)
+        return blocks, io + 16, oo + 16
+
+    @staticmethod
+    def plan_decode(stream_lengths, raw_sizes):
+        n = len(stream_lengths)
+        blocks = (Block * max(n, 1))()
+        io = oo = 0
+        for i in range(n):
+            blocks[i] = Block(io, oo, int(stream_lengths[i]), int(raw_sizes[i]), 0, 0)
+            io += _align(stream_lengths[i])
+            oo += _align(raw_sizes[i])
+        return blocks, io + 16, oo + 16
+
+    # ---- device calls (torch tensors in, stream-ordered on torch's current stream) ----
+    def encode_dev(self, d_in, d_out, blocks, n, d_out_len, d_out_pos, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().cramgpu_rans_encode_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), C.addressof(blocks), n,
+                                                      d_out_len.data_ptr(), d_out_pos.data_ptr(), s))
+
+    def decode_dev(self, d_in, d_out, blocks, n, d_out_len, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().cramgpu_rans_decode_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), C.addressof(blocks), n,
+                                                      d_out_len.data_ptr(), s))
+
+    def gather_dev(self, d_src, d_pos, d_len, n, max_len, d_dst, d_dst_off, align=16, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().cramgpu_gather_dev(self._h, d_src.data_ptr(), d_pos.data_ptr(), d_len.data_ptr(), n,
+                                                 int(max_len), align, d_dst.data_ptr(), d_dst.numel(),
+                                                 d_dst_off.data_ptr(), s))
+
+    # ---- host-arena batches (numpy) ----
+    def compress_many(self, datas, orders):
+        """[bytes], [order] -> [bytes] through cramgpu_rans_encode_batch (one H2D, one launch, one D2H)."""
+        n = len(datas)
+        if n == 0:
+            return []
+        blocks, in_bytes, out_bytes = self.plan_encode([len(d) for d in datas], orders)
+        arena = np.zeros(in_bytes, np.uint8)
+        for i, d in enumerate(datas):
+            arena[blocks[i].in_off:blocks[i].in_off + len(d)] = np.frombuffer(bytes(d), np.uint8)
+        out = np.zeros(out_bytes, np.uint8)
+        lens = np.zeros(n, np.int32)
+        _lib.check(_lib.lib().cramgpu_rans_encode_batch(self._h, arena.ctypes.data, in_bytes, out.ctypes.data, out_bytes,
+                                                        C.addressof(blocks), n, lens.ctypes.data))
+        res = []
+        for i in range(n):
+            if lens[i] < 0:
+                raise CramGpuError(int(lens[i]), "block %d" % i)
+            res.append(out[blocks[i].out_off:blocks[i].out_off + lens[i]].tobytes())
+        return res
+
+    def uncompress_many(self, streams):
+        n = len(streams)
+        if n == 0:
+            return []
+        raws = []
+        for s in streams:
+            b = np.frombuffer(bytes(s), np.uint8)
+            raws.append(0 if b.size == 0 else _lib.check(_lib.lib().cramgpu_rans_raw_size(b.ctypes.data, b.size)))
+        blocks, in_bytes, out_bytes = self.plan_decode([len(s) for s in streams], raws)
+        arena = np.zeros(in_bytes, np.uint8)
+        for i, s in enumerate(streams):
+            arena[blocks[i].in_off:blocks[i].in_off + len(s)] = np.frombuffer(bytes(s), np.uint8)
+        out = np.zeros(out_bytes, np.uint8)
+        lens = np.zeros(n, np.int32)
+        _lib.check(_lib.lib().cramgpu_rans_decode_batch(self._h, arena.ctypes.data, in_bytes, out.ctypes.data, out_bytes,
+                                                        C.addressof(blocks), n, lens.ctypes.data))
+        res = []
+        for i in range(n):
+            if lens[i] < 0:
+                raise CramGpuError(int(lens[i]), "block %d" % i)
+            res.append(out[blocks[i].out_off:blocks[i].out_off + lens[i]].tobytes())
+        return res

@@ -1,0 +1,259 @@
+/*
+ * cramgpu.h — C ABI of libcramgpu.so, the MI355X (gfx950) engine for the cramtools CRAM hot path.
+ *
+ * Every entry point names the reference interface it stands in for.  Citation forms:
+ *   src/...java:N                        a line of /root/reference/src/...
+ *   htsjdk!pkg/Class#method (L a-b)      a method of htsjdk 2.4.1 (lib/htsjdk-2.4.1.jar, bytecode only),
+ *                                        original source line numbers from its LineNumberTable
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - "host" pointers are ordinary process memory; "dev" pointers are HIP device memory on the context's GPU.
+ *   - stream arguments are hipStream_t passed as void* (NULL = the context's own stream).
+ *   - functions return >= 0 on success and a negative CRAMGPU_E_* code on failure; per-block results of
+ *     batch calls carry the same codes in out_len[].
+ *   - all functions are thread-safe on distinct contexts; one context serialises its calls internally.
+ */
+#ifndef CRAMGPU_H
+#define CRAMGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: the unchecked exceptions of the reference mapped to integers ---- */
+#define CRAMGPU_OK 0
+#define CRAMGPU_E_INPUT_LENGTH (-1)   /* RANS#uncompress L29-56: "Incorrect input length." */
+#define CRAMGPU_E_OUT_TOO_SMALL (-2)  /* RANS#uncompress: "Output buffer too small to fit N bytes." */
+#define CRAMGPU_E_INSUFFICIENT (-3)   /* RANS#allocateIfNeeded L79-85 / BufferOverflowException: "Insufficient buffer size." */
+#define CRAMGPU_E_ORDER (-4)          /* RANS.ORDER.fromInt: "Unknown rANS order: X" */
+#define CRAMGPU_E_CORRUPT (-5)        /* Java raises an index / buffer-underflow exception on a malformed stream */
+#define CRAMGPU_E_ARG (-6)            /* NULL pointer, misaligned offset, negative size */
+#define CRAMGPU_E_HIP (-7)            /* a HIP runtime call failed; cramgpu_last_error() has the text */
+#define CRAMGPU_E_NO_DEVICE (-8)      /* no gfx950 device visible: the library never falls back to a CPU path */
+#define CRAMGPU_E_JAVA_THROWS (-9)    /* record kernels: the reference would throw (index out of range, NPE) */
+
+#define CRAMGPU_ARENA_ALIGN 16        /* every block / stream offset inside a device arena is a multiple of this */
+
+typedef struct cramgpu_ctx cramgpu_ctx;
+
+/* ---- context ---- */
+/* One context per GPU (containers shard over GPUs by index, one context each).
+ * Has no counterpart in the reference (which is a single JVM); it owns the HIP stream, the pinned staging
+ * arenas, the device workspace of the persistent rANS kernels and the per-device rcp table. */
+cramgpu_ctx* cramgpu_open(int32_t device_index);
+void cramgpu_close(cramgpu_ctx* ctx);
+const char* cramgpu_last_error(void);
+int32_t cramgpu_device_count(void);
+/* CUs of the context's device and the number of resident rANS waves it launches. */
+int32_t cramgpu_info(cramgpu_ctx* ctx, int32_t* n_cu, int32_t* n_waves);
+
+/* =====================================================================================================
+ * Level 0 — block codec, synchronous, host buffers.
+ * Replaces htsjdk!io/ExternalCompression#rans (L89-90, L101-102) and #unrans (L112-113), i.e.
+ * htsjdk!encoding/rans/RANS#compress (L60-73) / #uncompress (L29-56), as called from
+ * htsjdk!build/ContainerFactory#buildSlice (L129-205), htsjdk!build/CompressionHeaderFactory
+ * #getBestExternalCompressor (L307-323) and htsjdk!structure/Block#uncompress (L228-262).
+ * These four use a process-wide default context on device 0 (created on first use).
+ * ===================================================================================================== */
+
+/* RANS#allocateIfNeeded L79-85: (int)(1.05*n + 257*257*3 + 4). */
+int32_t cramgpu_rans_bound(int32_t n);
+
+/* RANS#compress: out receives [order:1][compSize:LE32][rawSize:LE32][freq table][payload].
+ * n == 0 -> returns 0 (EMPTY_BUFFER); n < 4 -> order 0 whatever was asked.  Returns bytes written. */
+int32_t cramgpu_rans_compress(const uint8_t* in, int32_t n, int32_t order, uint8_t* out, int32_t cap);
+
+/* RANS#uncompress: returns the raw size, out must hold cramgpu_rans_raw_size() bytes. */
+int32_t cramgpu_rans_uncompress(const uint8_t* in, int32_t n, uint8_t* out, int32_t cap);
+
+/* LE32 at offset 5 of a stream (RANS#uncompress L29-56 header layout); 0 for an empty stream. */
+int32_t cramgpu_rans_raw_size(const uint8_t* in, int32_t n);
+
+/* =====================================================================================================
+ * Level 1 — batch of blocks (one call = all external blocks of one or many containers).
+ * The batch seam of the reference is the per-container compress loop of ContainerFactory#buildSlice L198-201,
+ * the eager uncompress of Block#readFromInputStream L78-100, and one level up the
+ * Function<OrderedByteArray,OrderedByteArray> of src/main/java/htsjdk/samtools/cram/paralell/
+ * BamToCram_OBA_Function.java:51-94 / CramToBam_OBA_Function.java:53-83.
+ * ===================================================================================================== */
+typedef struct {
+    int64_t in_off;   /* offset of the block's input in the input arena (multiple of CRAMGPU_ARENA_ALIGN) */
+    int64_t out_off;  /* offset of the block's output slot in the output arena (multiple of CRAMGPU_ARENA_ALIGN) */
+    int32_t in_len;   /* raw bytes (encode) / stream bytes (decode) */
+    int32_t out_cap;  /* slot size: >= cramgpu_rans_bound(in_len) for encode, >= raw size for decode */
+    int32_t order;    /* encode: 0 or 1 (RANS.ORDER); decode: ignored */
+    int32_t reserved;
+} cramgpu_block;
+
+/* Device-resident batch encode.  d_in / d_out are device arenas, blocks[] is a HOST array.
+ * After the call (stream-ordered) block b's stream occupies d_out[d_out_pos[b] .. + d_out_len[b]) — it is
+ * right-aligned inside its slot — or d_out_len[b] is a negative CRAMGPU_E_* code.
+ * d_out_len (int32[n]) and d_out_pos (int64[n]) are DEVICE arrays. */
+int32_t cramgpu_rans_encode_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,
+                                int32_t n_blocks, int32_t* d_out_len, int64_t* d_out_pos, void* stream);
+
+/* Device-resident batch decode: block b's raw bytes land at d_out[blocks[b].out_off ..); d_out_len[b] = raw size
+ * or a negative code. */
+int32_t cramgpu_rans_decode_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,
+                                int32_t n_blocks, int32_t* d_out_len, void* stream);
+
+/* Packs n variable-length pieces d_src[d_pos[b] .. + max(d_len[b],0)) back to back (each start rounded up to
+ * `align` bytes, a power of two >= 1) into d_dst, writes the start offsets to d_dst_off (int64[n+1], device).
+ * max_len = an upper bound of every d_len[b] (e.g. the largest out_cap).
+ * Used to shrink the encode output before the D2H copy.  No reference counterpart (Java's toByteArray L146-150
+ * is the per-block analogue). */
+int32_t cramgpu_gather_dev(cramgpu_ctx* ctx, const uint8_t* d_src, const int64_t* d_pos, const int32_t* d_len,
+                           int32_t n, int32_t max_len, int32_t align, uint8_t* d_dst, int64_t dst_cap,
+                           int64_t* d_dst_off, void* stream);
+
+/* Host-buffer batch (pinned staging + hipMemcpyAsync inside): in_arena/out_arena are host memory laid out by
+ * blocks[] exactly like the device arenas; on return out_len[b] holds the stream length (encode: the stream
+ * has been moved to the START of its slot, out_arena + blocks[b].out_off) or a negative code. */
+int32_t cramgpu_rans_encode_batch(cramgpu_ctx* ctx, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                                  int64_t out_bytes, const cramgpu_block* blocks, int32_t n_blocks,
+                                  int32_t* out_len);
+int32_t cramgpu_rans_decode_batch(cramgpu_ctx* ctx, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                                  int64_t out_bytes, const cramgpu_block* blocks, int32_t n_blocks,
+                                  int32_t* out_len);
+
+/* =====================================================================================================
+ * Level 2 — record kernels over one container in flat (structure-of-arrays) form.
+ * ===================================================================================================== */
+
+/* per-read flag bits */
+#define CRAMGPU_RF_UNMAPPED 1      /* SAMRecord.getReadUnmappedFlag() */
+#define CRAMGPU_RF_NULL_QUALS 2    /* SAMRecord.NULL_QUALS on input */
+#define CRAMGPU_RF_NO_BASES 4      /* encode: SAMRecord has no bases ("*"): treated as all 'N' */
+#define CRAMGPU_RF_UNKNOWN_BASES 8 /* decode: CramCompressionRecord.CF_UNKNOWN_BASES */
+#define CRAMGPU_RF_FORCE_QS 16     /* decode: CF_FORCE_PRESERVE_QS */
+#define CRAMGPU_RF_SKIP 32         /* record not processed */
+
+/* Reference bytes available to one container: d_ref[ref_off .. ref_off + ref_len) holds the 0-based reference
+ * positions [ref_start0, ref_start0 + ref_len) of the container's contig.  Encode passes the whole contig
+ * (ref_start0 = 0; Sam2CramRecordFactory#setRefBases, src/main/java/htsjdk/samtools/cram/CramSerilization.java:147-151),
+ * decode passes the ReferenceRegion window of CramNormalizer.java:212-226.  Positions at or beyond
+ * ref_start0 + ref_len read as past-the-end ('N'), exactly like the reference's length checks. */
+typedef struct {
+    int64_t ref_off;
+    int64_t ref_len;
+    int64_t ref_start0;
+} cramgpu_refwin;
+
+/* Reads of one or more containers, all arrays on the device, reads of a container contiguous.
+ * CIGAR elements are BAM-packed (len<<4 | op, op in MIDNSHP=X). */
+typedef struct {
+    int32_t n_reads;
+    int32_t n_cont;            /* number of containers (>= 1) */
+    int64_t n_bases;           /* bytes in bases / quals */
+    int32_t max_read_len;      /* largest read_len[r] */
+    int32_t reserved;
+    const uint8_t* bases;      /* concatenated read bases (ASCII) */
+    const uint8_t* quals;      /* concatenated phred bytes, same offsets as bases (may be NULL where unused) */
+    const int64_t* base_off;   /* [n_reads] offset of read r in bases/quals */
+    const int32_t* read_len;   /* [n_reads] */
+    const int32_t* aln_start;  /* [n_reads] 1-based alignment start, 0 = unplaced */
+    const uint8_t* rflags;     /* [n_reads] CRAMGPU_RF_* */
+    const uint8_t* mapq;       /* [n_reads] (lossy model only) */
+    const uint32_t* cigar;     /* packed CIGAR elements */
+    const int64_t* cigar_off;  /* [n_reads] */
+    const int32_t* n_cigar;    /* [n_reads] */
+    const int32_t* read_cont;  /* [n_reads] container index of read r, or NULL when n_cont == 1 */
+    const cramgpu_refwin* win; /* [n_cont] */
+} cramgpu_reads;
+
+/* Flat read features (the layout of src/main/java/htsjdk/samtools/cram/encoding/reader/ReadFeatureBuffer.java:41-100
+ * widened to fixed columns).  op = operator byte, pos = 1-based position in the read.
+ *   X: a = base | refBase<<8 | code<<16 (code 0xFF = not yet assigned)   D N H P: a = length
+ *   S, I: a = offset of the sequence in the read's bases (or in seq on decode), b = length
+ *   i: a = base      Q: a = score      B: a = base, b = score */
+typedef struct {
+    uint8_t* op;
+    int32_t* pos;
+    int32_t* a;
+    int32_t* b;
+    int64_t* off;   /* [n_reads + 1] feature range of read r = [off[r], off[r+1]) */
+    int64_t cap;    /* capacity of op/pos/a/b in features */
+} cramgpu_features;
+
+/* K3 — htsjdk!build/Sam2CramRecordFactory#createVariations (L205-264), #addSubstitutionsAndMaskedBases (L297-335),
+ * #addInsertion (L282-292), #addSoftClip (L268-272), htsjdk!build/Utils#normalizeBase (L31-49); called per record
+ * from src/main/java/htsjdk/samtools/cram/CramSerilization.java:154.  d_ref is the reference arena reads->win points
+ * into.  Also accumulates d_sub_hist[n_cont][25] (int64, [ref][base] over ACGTN x ACGTN, must be zeroed by the
+ * caller) for htsjdk!build/CompressionHeaderFactory#buildFrequencies (L196-209); may be NULL.
+ * Returns the feature count or a negative code (CRAMGPU_E_INSUFFICIENT when feats->cap is too small; feats->off is
+ * valid then and off[n_reads] is the capacity needed).  Synchronises the stream (the count comes back to the host). */
+int64_t cramgpu_extract_features_dev(cramgpu_ctx* ctx, const cramgpu_reads* reads, const uint8_t* d_ref,
+                                     cramgpu_features* feats, int64_t* d_sub_hist, void* stream);
+
+/* F3 — htsjdk!structure/SubstitutionMatrix#<init>([[J) (L38-57), #rank (L141-169): 25 counts -> 5 header bytes.
+ * Host function (25 numbers; the reference does the same per container). */
+void cramgpu_substitution_matrix(const int64_t* sub_hist, uint8_t* matrix5);
+
+/* htsjdk!encoding/writer/Writer#write (L139-261) picks matrix.code(ref, base) for each Substitution: fills bits 16..23
+ * of a[] for every X feature.  matrices = HOST array of n_cont x 5 header bytes; d_read_cont as in cramgpu_reads. */
+int32_t cramgpu_assign_codes_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32_t* d_read_cont, int32_t n_cont,
+                                 const cramgpu_features* feats, const uint8_t* matrices, void* stream);
+
+/* K4 / N1 — src/main/java/htsjdk/samtools/cram/build/CramNormalizer.java:335-441 (restoreReadBases), called from
+ * :137 and :239 with a ReferenceRegion window (d_wins[n_cont] into d_ref).  matrices = HOST n_cont x 5 bytes.
+ * d_seq/d_seq_off: bytes of S / I features (feature a = offset relative to d_seq_off[r]).
+ * d_status[r]: 0 bases written, 1 NULL_SEQUENCE, 2 skipped, CRAMGPU_E_JAVA_THROWS. */
+int32_t cramgpu_restore_bases_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32_t* d_read_len, const int32_t* d_aln_start,
+                                  const uint8_t* d_rflags, const int32_t* d_read_cont, int32_t n_cont,
+                                  const cramgpu_refwin* d_wins, const cramgpu_features* feats, const uint8_t* d_seq,
+                                  const int64_t* d_seq_off, const uint8_t* d_ref, const uint8_t* matrices, uint8_t* d_out,
+                                  const int64_t* d_out_off, int32_t* d_status, void* stream);
+
+/* N2 — CramNormalizer.java:287-333 (restoreQualityScores; default score 30 = '?'-'!', :141,:204).
+ * d_scores is in/out at d_out_off[r]; d_status[r]: 0 valid, 1 NULL_QUALS, 2 skipped. */
+int32_t cramgpu_restore_quals_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32_t* d_read_len, const uint8_t* d_rflags,
+                                  const cramgpu_features* feats, uint8_t default_qs, uint8_t* d_scores,
+                                  const int64_t* d_out_off, int32_t* d_status, void* stream);
+
+/* Q1 result — htsjdk!lossy/PreservationPolicy as a POD (parsed on the host by the caller, see
+ * src/main/java/htsjdk/samtools/cram/lossy/QualityScorePreservation.java:167-256). */
+typedef struct {
+    int32_t read_cat;    /* 0 none, 1 UNPLACED, 2 HIGHER_MAPPING_SCORE, 3 LOWER_MAPPING_SCORE, 4 ALL */
+    int32_t read_param;
+    int32_t treatment;   /* 0 PRESERVE, 1 BIN, 2 DROP */
+    int32_t n_base_cat;
+    int32_t base_cat[8]; /* 1 MATCH, 2 MISMATCH, 3 FLANKING_DELETION, 4 PILEUP, 5 LOWER_COVERAGE, 6 INSERTION */
+    int32_t base_param[8];
+} cramgpu_policy;
+
+/* Q1 — QualityScorePreservation.parsePolicies / parseSinglePolicy / readTreatment (:139-256): spec string ->
+ * policies sorted like the reference (stable, by treatment ordinal descending).  Host function.
+ * Returns the number of policies (<= max_pol) or CRAMGPU_E_ARG for an unknown category letter. */
+int32_t cramgpu_parse_policies(const char* spec, cramgpu_policy* out, int32_t max_pol);
+
+/* K5 / Q2 — QualityScorePreservation.addQualityScores :276-301, addQS :332-489, applyTreatment :263-274,
+ * lossy/Binning.java:63-71, ref/ReferenceTracks.java:127-155 (baseAt semantics; coverage / mismatch tracks read 0).
+ * d_wpos[r] = 1-based ReferenceTracks window position in force when read r is processed (ReferenceTracks.java:87-133;
+ * sequential host state, computed by cramgpu_tracks_windows); reads->win must cover the whole contig.  pol = HOST array.
+ * Outputs: d_scores (0xFF = hole) at base_off[r],
+ * d_force[r], d_status[r] (0 ok, 1 NULL_QUALS, 2 skipped, CRAMGPU_E_JAVA_THROWS). */
+int32_t cramgpu_lossy_quals_dev(cramgpu_ctx* ctx, const cramgpu_reads* reads, const uint8_t* d_ref,
+                                const int32_t* d_wpos, int32_t window, const cramgpu_policy* pol, int32_t n_pol,
+                                uint8_t* d_scores, uint8_t* d_force, int32_t* d_status, void* stream);
+
+/* ReferenceTracks.ensureRange / moveForwardTo (ReferenceTracks.java:87-133) replayed over the reads of a container in
+ * order: HOST arrays in, wpos[] out.  Returns 0 or -(r+1) when the reference would throw at read r. */
+int32_t cramgpu_tracks_windows(int32_t n_reads, const int32_t* aln_start, const int32_t* aln_span, const uint8_t* rflags,
+                               const uint8_t* mapq, const cramgpu_policy* pol, int32_t n_pol, int64_t ref_len,
+                               int32_t window, int32_t* wpos);
+
+/* Tail of addQualityScores (:288-299): appends BaseQualityScore features for non-forced reads and stable-sorts by
+ * position.  Returns the merged feature count (synchronises the stream) or a negative code. */
+int64_t cramgpu_merge_quality_features_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32_t* d_read_len,
+                                           const int64_t* d_base_off, const uint8_t* d_scores, const uint8_t* d_force,
+                                           const int32_t* d_qstatus, const cramgpu_features* in, cramgpu_features* out,
+                                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRAMGPU_H */
