@@ -112,6 +112,8 @@ struct cramgpu_ctx {
     PinBuf<int64_t> h_total;
     DevBuf<uint8_t> d_small;   // matrix tables, policies
     DevBuf<uint8_t> d_maskws;
+    PinBuf<uint32_t> dbg;      // CRAMGPU_DEBUG=1 progress markers
+    bool debug = false;
 };
 
 namespace {
@@ -166,6 +168,9 @@ int rans_run(cramgpu_ctx* c, bool encode, const uint8_t* d_in, uint8_t* d_out, c
     a.ticket = ticket;
     a.rcp_tab = c->rcp_tab.p;
     a.tab_bytes = c->tab_bytes;
+    a.stop_phase = env_int("CRAMGPU_STOP_PHASE", 0);
+    a.dbg = c->debug ? c->dbg.p : nullptr;
+    if (c->debug) memset(c->dbg.p, 0, 64 * sizeof(uint32_t));
     if (encode) {
         a.gscratch = c->enc_gs.p;
         HIPCHK(launch_rans_encode(a, std::min(n, c->n_waves_enc), c->enc_lds, s));
@@ -224,6 +229,8 @@ cramgpu_ctx* cramgpu_open(int32_t device_index) {
     c->dec_lds = rans_decode_fixed_lds() + c->tab_bytes;
     c->enc_wpc = std::max(1, std::min(env_int("CRAMGPU_ENC_WAVES_PER_CU", 16), (int)(lds_per_cu / (c->enc_lds + 512))));
     c->dec_wpc = std::max(1, std::min(env_int("CRAMGPU_DEC_WAVES_PER_CU", 16), (int)(lds_per_cu / (c->dec_lds + 512))));
+    c->debug = env_int("CRAMGPU_DEBUG", 0) != 0;
+    if (c->debug && c->dbg.reserve(1024) != hipSuccess) c->debug = false;
     c->n_waves_enc = c->n_cu * c->enc_wpc;
     c->n_waves_dec = c->n_cu * c->dec_wpc;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -345,7 +352,15 @@ static int32_t host_batch(cramgpu_ctx* c, bool encode, const uint8_t* in_arena, 
                          c->d_err.p, (int32_t)std::min<int64_t>(max_cap, 0x7fffffff), s));
     HIPCHK(hipMemcpyAsync(c->h_len.p, c->d_len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(c->h_off.p, c->d_off.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    {
+        hipError_t se = hipStreamSynchronize(s);
+        if (c->debug) {
+            fprintf(stderr, "[cramgpu debug] sync=%d markers:", (int)se);
+            for (int i = 0; i < 8; i++) fprintf(stderr, " %u(0x%x)", c->dbg.p[i], c->dbg.p[i]);
+            fprintf(stderr, "\n");
+        }
+        if (se != hipSuccess) return fail(CRAMGPU_E_HIP, "hipStreamSynchronize(s)", se);
+    }
     const int64_t packed = c->h_off.p[n];
     HIPCHK(c->h_stage.reserve((size_t)packed + 16));
     HIPCHK(hipMemcpyAsync(c->h_stage.p, c->d_pack.p, (size_t)packed, hipMemcpyDeviceToHost, s));

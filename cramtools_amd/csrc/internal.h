@@ -5,6 +5,26 @@
 
 #include "../../include/cramgpu.h"
 
+// dynamic LDS of a kernel (the host-side sanitizer harness under tests/cpu_sim substitutes a heap buffer)
+#ifdef HIP_SIM
+#define CRAMGPU_DYN_LDS(name) uint8_t* name = hipsim::dyn_lds()
+#else
+#define CRAMGPU_DYN_LDS(name) extern __shared__ __align__(16) uint8_t name[]
+#endif
+
+// progress marker into pinned host memory (debug builds of a run only; dbg is NULL otherwise)
+#ifdef HIP_SIM
+#define CRAMGPU_MARK(dbg, i, v) do { if (dbg) (dbg)[i] = (uint32_t)(v); } while (0)
+#else
+#define CRAMGPU_MARK(dbg, i, v)                                         \
+    do {                                                                \
+        if (dbg) {                                                      \
+            ((volatile uint32_t*)(dbg))[i] = (uint32_t)(v);             \
+            __threadfence_system();                                     \
+        }                                                               \
+    } while (0)
+#endif
+
 #define RANS_TF_SHIFT 12
 #define RANS_TOTFREQ 4096
 #define RANS_BYTE_L (1u << 23)
@@ -27,6 +47,8 @@ struct RansArgs {
     uint8_t* gscratch;          // n_waves x {ENC,DEC}_GSCRATCH_BYTES
     const uint32_t* rcp_tab;    // [4096] Encoding#RansEncSymbolInit rcp_freq per freq
     int32_t tab_bytes;          // bytes of the LDS table region
+    int32_t stop_phase;         // CRAMGPU_STOP_PHASE debugging aid (0 = off)
+    uint32_t* dbg;              // CRAMGPU_DEBUG=1: pinned host words for progress markers, else NULL
 };
 
 // launchers (defined in the .hip files)

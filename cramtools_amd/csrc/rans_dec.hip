@@ -335,7 +335,7 @@ __device__ void decode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* g
 }
 
 __global__ __launch_bounds__(64) void rans_decode_kernel(RansArgs a) {
-    extern __shared__ __align__(16) uint8_t smem[];
+    CRAMGPU_DYN_LDS(smem);
     uint8_t* gs = a.gscratch + (size_t)blockIdx.x * DEC_GSCRATCH_BYTES;
     for (;;) {
         uint32_t t = 0;

@@ -19,6 +19,8 @@
 //      Bytes are written from the end of the block's slot downwards, which realises Utils#reverse for free.
 // Order-1 tables live in LDS over the compacted alphabet (present symbols + 0) when n*(n|1)*12 B fits the table
 // region, else in a per-wave global scratch over the full 256x256 alphabet.
+#include <climits>
+
 #include "internal.h"
 
 namespace {
@@ -30,7 +32,8 @@ struct EncFixedLds {
     uint2 stageB[64];     // cmpl_freq, rcp_shift-32
     uint32_t xs[64];      // state of (step, lane) before the step
     uint32_t rowT[256];   // order-1 row totals (0 = context absent)
-    uint32_t rowoff[256]; // serialised offset of each row
+    uint32_t rowoff[256]; // serialised length of each row
+    uint32_t rowhdr[256]; // context-level header of each row: count | byte0 << 8 | byte1 << 16
     uint8_t dmap[256];    // byte value -> dense index
     uint8_t syml[256];    // dense index -> byte value
 };
@@ -126,9 +129,10 @@ __device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* 
 }
 
 // order-1 pair counts: cnt[row(prev)*stride + col(cur)] with prev = 0 before the first byte
-// (Frequencies#calcFrequencies_o1 L149-168).  DENSE: indices through dmap (LDS tables); else raw bytes (global table).
-template <bool DENSE>
-__device__ void hist_o1(const uint8_t* src, int32_t n, uint32_t* cnt, int stride, const uint8_t* dmap, uint32_t* rep,
+// (Frequencies#calcFrequencies_o1 L149-168); indices go through dmap (identity for the 256 x 256 global table).
+// Deliberately ONE non-inlined body over generic pointers for the LDS and the global tables, like tables_o1: the
+// machine code the wide-alphabet path runs is then the code every small-alphabet block has already exercised.
+__device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n, uint32_t* cnt, int stride, const uint8_t* dmap, uint32_t* rep,
                         int R, int rstride, int cells) {
     const int l = lane_id();
     uint32_t* my = cnt;
@@ -141,14 +145,14 @@ __device__ void hist_o1(const uint8_t* src, int32_t n, uint32_t* cnt, int stride
     for (int32_t i = l * 16; i < n16; i += 64 * 16) {
         uint4 v = *reinterpret_cast<const uint4*>(src + i);
         uint32_t prev = i ? src[i - 1] : 0u;
-        uint32_t row = (DENSE ? (uint32_t)dmap[prev] : prev) * (uint32_t)stride;
+        uint32_t row = (uint32_t)dmap[prev] * (uint32_t)stride;
         uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
 #pragma unroll
             for (int bshift = 0; bshift < 32; bshift += 8) {
                 uint32_t c = (w[k] >> bshift) & 255u;
-                uint32_t col = DENSE ? (uint32_t)dmap[c] : c;
+                uint32_t col = (uint32_t)dmap[c];
                 atomicAdd(&my[row + col], 1u);
                 row = col * (uint32_t)stride;
             }
@@ -157,14 +161,14 @@ __device__ void hist_o1(const uint8_t* src, int32_t n, uint32_t* cnt, int stride
     if (n16 + l < n) {
         int32_t i = n16 + l;
         uint32_t prev = i ? src[i - 1] : 0u, c = src[i];
-        uint32_t row = DENSE ? (uint32_t)dmap[prev] : prev, col = DENSE ? (uint32_t)dmap[c] : c;
+        uint32_t row = (uint32_t)dmap[prev], col = (uint32_t)dmap[c];
         atomicAdd(&my[row * stride + col], 1u);
     }
     if (l == 0) {  // L170-173: the three quarter-start symbols are also counted in context 0
         const int32_t q = n >> 2;
         for (int k = 1; k < 4; k++) {
             uint32_t c = src[k * q];
-            atomicAdd(&my[DENSE ? (uint32_t)dmap[c] : c], 1u);
+            atomicAdd(&my[(uint32_t)dmap[c]], 1u);
         }
     }
     __syncthreads();
@@ -219,11 +223,12 @@ __device__ int row_body(const uint32_t* c, int n, const uint8_t* syml, uint8_t* 
 
 // order-1: normalise rows (L175-193), serialise (writeFrequencies_o1 L269-328), build symbols (buildSyms_o1 L248-265).
 // Returns the table length; table bytes go to tabdst.
-__device__ int32_t tables_o1(uint32_t* cnt, uint2* ent, int nrows, int n, int stride, EncFixedLds* L, uint8_t* tabdst,
-                             const uint32_t* rcp_tab) {
+__device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent, int nrows, int n, int stride, EncFixedLds* L, uint8_t* tabdst,
+                             const uint32_t* rcp_tab, uint32_t* dbg = nullptr, int stop = 0) {
     const int l = lane_id();
     const int rpl = (nrows + 63) >> 6;  // rows per lane, contiguous so a lane scan gives row order
     // normalise
+#pragma unroll 1
     for (int k = 0; k < rpl; k++) {
         int row = l * rpl + k;
         if (row >= nrows) break;
@@ -250,56 +255,64 @@ __device__ int32_t tables_o1(uint32_t* cnt, uint2* ent, int nrows, int n, int st
         c[M] = (uint32_t)((int32_t)c[M] + (RANS_TOTFREQ - t2));
     }
     __syncthreads();
-    // serialised length of each present row: context header (index byte, run byte) + body
+    if (stop == 3) return -53;
+    if (lane_id() == 0) CRAMGPU_MARK(dbg, 1, 50);
+    // serialised length of each present row: context header (index byte, run byte) + body.  The header is kept in
+    // LDS (count | byte0 << 8 | byte1 << 16, in the high half of rowoff) so that the write pass only replays it.
     uint32_t mylen = 0;
+#pragma unroll 1
     for (int k = 0; k < rpl; k++) {
-        int row = l * rpl + k;
+        const int row = l * rpl + k;
         if (row >= nrows) break;
-        uint32_t len = 0;
+        uint32_t len = 0, hdr = 0;
         if (L->rowT[row] != 0) {
-            int v = L->syml[row];
-            bool link = v > 0 && row > 0 && L->syml[row - 1] == v - 1 && L->rowT[row - 1] != 0;
+            const int v = L->syml[row];
+            const bool link = v > 0 && row > 0 && L->syml[row - 1] == v - 1 && L->rowT[row - 1] != 0;
             if (!link) {
-                len = 1;
+                hdr = 1u | ((uint32_t)v << 8);
             } else {
-                int pv = v - 1;
-                bool plink = pv > 0 && row > 1 && L->syml[row - 2] == pv - 1 && L->rowT[row - 2] != 0;
-                len = plink ? 0 : 2;
+                const int pv = v - 1;
+                const bool plink = pv > 0 && row > 1 && L->syml[row - 2] == pv - 1 && L->rowT[row - 2] != 0;
+                if (!plink) {
+                    int kk = row + 1;
+                    while (kk < nrows && L->syml[kk] == L->syml[kk - 1] + 1 && L->rowT[kk] != 0) kk++;
+                    hdr = 2u | ((uint32_t)v << 8) | ((uint32_t)(kk - (row + 1)) << 16);
+                }
             }
-            len += (uint32_t)row_body<false>(cnt + row * stride, n, L->syml, nullptr);
+            len = (hdr & 3u) + (uint32_t)row_body<false>(cnt + row * stride, n, L->syml, nullptr);
         }
         L->rowoff[row] = len;
+        L->rowhdr[row] = hdr;
         mylen += len;
     }
     uint32_t total;
     uint32_t base = wave_excl_scan(mylen, total);
     __syncthreads();
+    if (lane_id() == 0) {
+        CRAMGPU_MARK(dbg, 1, 51);
+        CRAMGPU_MARK(dbg, 2, total);
+    }
+    if (stop == 4) return -54;
+#pragma unroll 1
     for (int k = 0; k < rpl; k++) {
-        int row = l * rpl + k;
+        const int row = l * rpl + k;
         if (row >= nrows) break;
-        uint32_t len = L->rowoff[row];
-        if (L->rowT[row] != 0) {
+        const uint32_t len = L->rowoff[row];
+        if (len != 0) {
+            const uint32_t hdr = L->rowhdr[row];
             uint8_t* d = tabdst + base;
-            int v = L->syml[row];
-            bool link = v > 0 && row > 0 && L->syml[row - 1] == v - 1 && L->rowT[row - 1] != 0;
-            if (!link) {
-                *d++ = (uint8_t)v;
-            } else {
-                int pv = v - 1;
-                bool plink = pv > 0 && row > 1 && L->syml[row - 2] == pv - 1 && L->rowT[row - 2] != 0;
-                if (!plink) {
-                    int kk = row + 1;
-                    while (kk < nrows && L->syml[kk] == L->syml[kk - 1] + 1 && L->rowT[kk] != 0) kk++;
-                    *d++ = (uint8_t)v;
-                    *d++ = (uint8_t)(kk - (row + 1));
-                }
-            }
-            row_body<true>(cnt + row * stride, n, L->syml, d);
+            if ((hdr & 3u) >= 1) d[0] = (uint8_t)(hdr >> 8);
+            if ((hdr & 3u) == 2) d[1] = (uint8_t)(hdr >> 16);
+            row_body<true>(cnt + row * stride, n, L->syml, d + (hdr & 3u));
         }
         base += len;
     }
     if (l == 0) tabdst[total] = 0;
+    if (l == 0) CRAMGPU_MARK(dbg, 1, 52);
+    __syncthreads();
+    if (stop == 5) return -55;
     // encoder symbols
+#pragma unroll 1
     for (int k = 0; k < rpl; k++) {
         int row = l * rpl + k;
         if (row >= nrows) break;
@@ -315,6 +328,7 @@ __device__ int32_t tables_o1(uint32_t* cnt, uint2* ent, int nrows, int n, int st
         }
     }
     __syncthreads();
+    if (stop == 6) return -56;
     return (int32_t)total + 1;
 }
 
@@ -381,7 +395,7 @@ enum { MODE_O0 = 0, MODE_O1_LDS = 1, MODE_O1_GLOBAL = 2 };
 // Returns payload length (including the 16 state bytes) or a negative code.  Payload is written downwards from pend.
 template <int MODE>
 __device__ int32_t encode_stream(const uint8_t* src, int32_t n, const uint2* ent, int stride, EncFixedLds* L,
-                                 uint8_t* pend, int32_t room) {
+                                 uint8_t* pend, int32_t room, uint32_t* dbg = nullptr) {
     const int l = lane_id();
     const int t = l >> 2, j = 3 - (l & 3);
     const int32_t q = n >> 2;
@@ -396,6 +410,7 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n, const uint2* ent
     int32_t run = 0;
     const int32_t limit = room - 16;
     for (int32_t ub = 0; ub < U; ub += kSteps) {
+        if (l == 0) CRAMGPU_MARK(dbg, 3, 0x1000 + ub);
         const int32_t u = ub + t;
         bool act = u < U;
         int32_t pos = 0;
@@ -431,6 +446,7 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n, const uint2* ent
         L->stageA[t * 4 + j] = A;
         L->stageB[t * 4 + j] = B;
         __syncthreads();
+        if (l == 0) CRAMGPU_MARK(dbg, 3, 0x2000 + ub);
         if (l < 4) {
 #pragma unroll
             for (int tt = 0; tt < kSteps; tt++) {
@@ -451,6 +467,7 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n, const uint2* ent
         const int32_t tot = __popcll(m1) + __popcll(m2);
         if (run + tot > limit) return CRAMGPU_E_INSUFFICIENT;
         const int32_t idx = run + (int32_t)(mbcnt(m1) + mbcnt(m2));
+        if (l == 0) CRAMGPU_MARK(dbg, 3, 0x3000 + ub);
         if (nb >= 1) pend[-1 - idx] = (uint8_t)xv;
         if (nb == 2) pend[-2 - idx] = (uint8_t)(xv >> 8);
         run += tot;
@@ -466,14 +483,146 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n, const uint2* ent
     return run + 16;
 }
 
-__device__ void encode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* gs) {
+// One block's coding work is split into three non-inlined functions (order 0, order 1 with LDS tables, order 1 with
+// global tables) so that each gets its own register allocation: inlined into one body the kernel needed ~50 SGPR
+// spills, and the wide-alphabet path misbehaved on hardware in exactly that build.
+struct Blk {
+    const uint8_t* src;
+    uint8_t* slot;
+    uint8_t* gs;
+    const uint32_t* rcp_tab;
+    uint32_t* dbg;
+    int32_t n, cap, tab_bytes, stop;
+};
+struct Res {
+    int32_t tab_len, pay_len;
+};
+
+__device__ __attribute__((noinline)) Res run_o0(Blk B) {
+    CRAMGPU_DYN_LDS(smem);
     const int l = lane_id();
     EncFixedLds* L = reinterpret_cast<EncFixedLds*>(smem);
     uint8_t* tab = smem + sizeof(EncFixedLds);
+    uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);    // 256 words
+    uint2* ent0 = reinterpret_cast<uint2*>(tab + 1024);  // 256 x 8 B
+    uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
+    int R0 = 1;
+    while (R0 < 16 && (1024 + 2048 + 2 * R0 * 1024) <= B.tab_bytes) R0 <<= 1;
+    hist_o0(B.src, B.n, cnt0, rep0, R0);
+    for (int i = l; i < 256; i += 64) L->syml[i] = (uint8_t)i;
+    __syncthreads();
+    Res r;
+    r.tab_len = tables_o0(cnt0, ent0, B.n, L, B.slot + 9, B.rcp_tab);
+    if (9 + r.tab_len + 16 > B.cap)
+        r.pay_len = CRAMGPU_E_INSUFFICIENT;
+    else
+        r.pay_len = encode_stream<MODE_O0>(B.src, B.n, ent0, 256, L, B.slot + B.cap, B.cap - 9 - r.tab_len);
+    return r;
+}
+
+__device__ __attribute__((noinline)) Res run_o1_global(Blk B) {
+    CRAMGPU_DYN_LDS(smem);
+    const int l = lane_id();
+    EncFixedLds* L = reinterpret_cast<EncFixedLds*>(smem);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(B.gs);
+    uint2* ent = reinterpret_cast<uint2*>(B.gs + 256 * 1024);
+    uint4* z = reinterpret_cast<uint4*>(B.gs);
+    for (int i = l; i < 256 * 1024 / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
+    for (int i = l; i < 256; i += 64) {
+        L->syml[i] = (uint8_t)i;
+        L->dmap[i] = (uint8_t)i;
+    }
+    __threadfence();
+    __syncthreads();
+    Res r{0, 0};
+    const int stop = B.stop;  // debugging aid: leave the path after phase `stop`
+    if (stop == 1) r.pay_len = -51;
+    if (r.pay_len == 0) {
+        hist_o1(B.src, B.n, cnt, 256, L->dmap, nullptr, 1, 0, 0);
+        __threadfence();
+        __syncthreads();
+        if (stop == 2) r.pay_len = -52;
+    }
+    if (r.pay_len == 0) {
+        r.tab_len = tables_o1(cnt, ent, 256, 256, 256, L, B.slot + 9, B.rcp_tab, B.dbg, stop);
+        __threadfence();
+        __syncthreads();
+        if (r.tab_len < 0) r.pay_len = r.tab_len;
+    }
+    if (r.pay_len == 0) {
+        if (9 + r.tab_len + 16 > B.cap)
+            r.pay_len = CRAMGPU_E_INSUFFICIENT;
+        else
+            r.pay_len = encode_stream<MODE_O1_GLOBAL>(B.src, B.n, ent, 256, L, B.slot + B.cap, B.cap - 9 - r.tab_len, B.dbg);
+        if (stop == 7 && r.pay_len >= 0) r.pay_len = -57;
+    }
+    return r;
+}
+
+// returns pay_len == INT32_MIN when the alphabet does not fit the LDS table region
+__device__ __attribute__((noinline)) Res run_o1_lds(Blk B) {
+    CRAMGPU_DYN_LDS(smem);
+    const int l = lane_id();
+    EncFixedLds* L = reinterpret_cast<EncFixedLds*>(smem);
+    uint8_t* tab = smem + sizeof(EncFixedLds);
+    uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);
+    uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
+    int R0 = 1;
+    while (R0 < 16 && (1024 + 2048 + 2 * R0 * 1024) <= B.tab_bytes) R0 <<= 1;
+    hist_o0(B.src, B.n, cnt0, rep0, R0);
+    // dense alphabet = present symbols plus 0 (context 0 always exists)
+    uint32_t present = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int jj = l * 4 + k;
+        bool p = cnt0[jj] != 0 || jj == 0;
+        present |= (p ? 1u : 0u) << k;
+        mine += p ? 1u : 0u;
+    }
+    uint32_t nsym;
+    uint32_t di = wave_excl_scan(mine, nsym);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int jj = l * 4 + k;
+        if (present & (1u << k)) {
+            L->dmap[jj] = (uint8_t)di;
+            L->syml[di] = (uint8_t)jj;
+            di++;
+        } else {
+            L->dmap[jj] = 0;
+        }
+    }
+    __syncthreads();
+    const int ns = (int)nsym;
+    const int stride = ns | 1;
+    const int cells = ns * stride;
+    Res r{0, INT32_MIN};
+    if (12 * cells + 16 > B.tab_bytes) return r;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(tab);
+    const int ent_off = (4 * cells + 15) & ~15;
+    uint2* ent = reinterpret_cast<uint2*>(tab + ent_off);
+    const int rep_off = ent_off + 8 * cells;
+    const int rstride = cells | 1;
+    int R = 1;
+    while (R < 32 && rep_off + 2 * R * rstride * 4 <= B.tab_bytes) R <<= 1;
+    uint32_t* rep = reinterpret_cast<uint32_t*>(tab + rep_off);
+    for (int i = l; i < cells; i += 64) cnt[i] = 0;
+    __syncthreads();
+    hist_o1(B.src, B.n, cnt, stride, L->dmap, rep, R, rstride, cells);
+    r.tab_len = tables_o1(cnt, ent, ns, ns, stride, L, B.slot + 9, B.rcp_tab);
+    if (9 + r.tab_len + 16 > B.cap)
+        r.pay_len = CRAMGPU_E_INSUFFICIENT;
+    else
+        r.pay_len = encode_stream<MODE_O1_LDS>(B.src, B.n, ent, stride, L, B.slot + B.cap, B.cap - 9 - r.tab_len);
+    return r;
+}
+
+__device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
+    const int l = lane_id();
     const cramgpu_block d = a.desc[b];
     const int32_t n = d.in_len;
     int order = d.order;
-    const uint8_t* src = a.in + d.in_off;
     uint8_t* slot = a.out + d.out_off;
     const int32_t cap = d.out_cap;
     int32_t result;
@@ -488,85 +637,19 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* g
         if (n < 4) order = 0;  // RANS#compress L63-64
         uint8_t* tabdst = slot + 9;
         uint8_t* pend = slot + cap;
-        int32_t tab_len, pay_len;
-        uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);              // 256 words
-        uint2* ent0 = reinterpret_cast<uint2*>(tab + 1024);            // 256 x 8 B
-        uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
-        int R0 = 1;
-        while (R0 < 16 && (1024 + 2048 + 2 * R0 * 1024) <= a.tab_bytes) R0 <<= 1;
-        hist_o0(src, n, cnt0, rep0, R0);
+        Blk B{a.in + d.in_off, slot, gs, a.rcp_tab, a.dbg, n, cap, a.tab_bytes, a.stop_phase};
+        Res r;
         if (order == 0) {
-            for (int i = l; i < 256; i += 64) L->syml[i] = (uint8_t)i;
-            __syncthreads();
-            tab_len = tables_o0(cnt0, ent0, n, L, tabdst, a.rcp_tab);
-            if (9 + tab_len + 16 > cap)
-                pay_len = CRAMGPU_E_INSUFFICIENT;
-            else
-                pay_len = encode_stream<MODE_O0>(src, n, ent0, 256, L, pend, cap - 9 - tab_len);
+            r = run_o0(B);
         } else {
-            // dense alphabet = present symbols plus 0 (context 0 always exists)
-            uint32_t present = 0, mine = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int jj = l * 4 + k;
-                bool p = cnt0[jj] != 0 || jj == 0;
-                present |= (p ? 1u : 0u) << k;
-                mine += p ? 1u : 0u;
-            }
-            uint32_t nsym;
-            uint32_t di = wave_excl_scan(mine, nsym);
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int jj = l * 4 + k;
-                if (present & (1u << k)) {
-                    L->dmap[jj] = (uint8_t)di;
-                    L->syml[di] = (uint8_t)jj;
-                    di++;
-                } else {
-                    L->dmap[jj] = 0;
-                }
-            }
-            __syncthreads();
-            const int ns = (int)nsym;
-            const int stride = ns | 1;
-            const int cells = ns * stride;
-            if (12 * cells + 16 <= a.tab_bytes) {
-                uint32_t* cnt = reinterpret_cast<uint32_t*>(tab);
-                const int ent_off = (4 * cells + 15) & ~15;
-                uint2* ent = reinterpret_cast<uint2*>(tab + ent_off);
-                const int rep_off = ent_off + 8 * cells;
-                const int rstride = cells | 1;
-                int R = 1;
-                while (R < 32 && rep_off + 2 * R * rstride * 4 <= a.tab_bytes) R <<= 1;
-                uint32_t* rep = reinterpret_cast<uint32_t*>(tab + rep_off);
-                for (int i = l; i < cells; i += 64) cnt[i] = 0;
-                __syncthreads();
-                hist_o1<true>(src, n, cnt, stride, L->dmap, rep, R, rstride, cells);
-                tab_len = tables_o1(cnt, ent, ns, ns, stride, L, tabdst, a.rcp_tab);
-                if (9 + tab_len + 16 > cap)
-                    pay_len = CRAMGPU_E_INSUFFICIENT;
-                else
-                    pay_len = encode_stream<MODE_O1_LDS>(src, n, ent, stride, L, pend, cap - 9 - tab_len);
-            } else {
-                uint32_t* cnt = reinterpret_cast<uint32_t*>(gs);
-                uint2* ent = reinterpret_cast<uint2*>(gs + 256 * 1024);
-                uint4* z = reinterpret_cast<uint4*>(gs);
-                for (int i = l; i < 256 * 1024 / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
-                for (int i = l; i < 256; i += 64) L->syml[i] = (uint8_t)i;
-                __threadfence();
-                __syncthreads();
-                hist_o1<false>(src, n, cnt, 256, nullptr, nullptr, 1, 0, 0);
-                __threadfence();
-                __syncthreads();
-                tab_len = tables_o1(cnt, ent, 256, 256, 256, L, tabdst, a.rcp_tab);
-                __threadfence();
-                __syncthreads();
-                if (9 + tab_len + 16 > cap)
-                    pay_len = CRAMGPU_E_INSUFFICIENT;
-                else
-                    pay_len = encode_stream<MODE_O1_GLOBAL>(src, n, ent, 256, L, pend, cap - 9 - tab_len);
-            }
+            r = run_o1_lds(B);
+            if (r.pay_len == INT32_MIN) r = run_o1_global(B);
+        }
+        const int32_t tab_len = r.tab_len, pay_len = r.pay_len;
+        if (l == 0) {
+            CRAMGPU_MARK(a.dbg, 0, 8);
+            CRAMGPU_MARK(a.dbg, 4, tab_len);
+            CRAMGPU_MARK(a.dbg, 5, pay_len);
         }
         if (pay_len < 0) {
             result = pay_len;
@@ -597,20 +680,21 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* g
         }
     }
     if (l == 0) {
+        CRAMGPU_MARK(a.dbg, 0, 9);
         a.out_len[b] = result;
         a.out_pos[b] = pos;
+        CRAMGPU_MARK(a.dbg, 0, 10);
     }
 }
 
 __global__ __launch_bounds__(64) void rans_encode_kernel(RansArgs a) {
-    extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* gs = a.gscratch + (size_t)blockIdx.x * ENC_GSCRATCH_BYTES;
     for (;;) {
         uint32_t t = 0;
         if (threadIdx.x == 0) t = atomicAdd(a.ticket, 1u);
         t = __shfl(t, 0);
         if (t >= (uint32_t)a.n_blocks) break;  // every wave reaches this: the queue only grows
-        encode_block(a, a.perm[t], smem, gs);
+        encode_block(a, a.perm[t], gs);
         __syncthreads();
     }
 }
