@@ -224,7 +224,7 @@ __device__ int row_body(const uint32_t* c, int n, const uint8_t* syml, uint8_t* 
 // order-1: normalise rows (L175-193), serialise (writeFrequencies_o1 L269-328), build symbols (buildSyms_o1 L248-265).
 // Returns the table length; table bytes go to tabdst.
 __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent, int nrows, int n, int stride, EncFixedLds* L, uint8_t* tabdst,
-                             const uint32_t* rcp_tab, uint32_t* dbg = nullptr, int stop = 0) {
+                             const uint32_t* rcp_tab, int32_t tab_cap, uint32_t* dbg = nullptr, int stop = 0) {
     const int l = lane_id();
     const int rpl = (nrows + 63) >> 6;  // rows per lane, contiguous so a lane scan gives row order
     // normalise
@@ -293,12 +293,15 @@ __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent
         CRAMGPU_MARK(dbg, 2, total);
     }
     if (stop == 4) return -54;
+    // RANS#allocateIfNeeded L79-85 budgets 257*257*3 bytes for the table; nothing larger can be a valid table, and
+    // every row is written strictly inside [0, total): a stray length can therefore never leave the block's slot
+    if (total > 257u * 257u * 3u || (int64_t)total + 1 > (int64_t)tab_cap) return CRAMGPU_E_INSUFFICIENT;
 #pragma unroll 1
     for (int k = 0; k < rpl; k++) {
         const int row = l * rpl + k;
         if (row >= nrows) break;
         const uint32_t len = L->rowoff[row];
-        if (len != 0) {
+        if (len != 0 && base + len <= total) {
             const uint32_t hdr = L->rowhdr[row];
             uint8_t* d = tabdst + base;
             if ((hdr & 3u) >= 1) d[0] = (uint8_t)(hdr >> 8);
@@ -335,7 +338,7 @@ __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent
 // order-0: Frequencies#calcFrequencies_o0 L109-145, #writeFrequencies_o0 L215-244, #buildSyms_o0 L197-211.
 // cnt[256] raw counts in, normalised out; ent[256].
 __device__ int32_t tables_o0(uint32_t* cnt, uint2* ent, int32_t n_in, EncFixedLds* L, uint8_t* tabdst,
-                             const uint32_t* rcp_tab) {
+                             const uint32_t* rcp_tab, int32_t tab_cap) {
     const int l = lane_id();
     const unsigned long long tr =
         ((unsigned long long)RANS_TOTFREQ << 31) / (unsigned long long)n_in + (unsigned long long)((1 << 30) / n_in);
@@ -381,7 +384,10 @@ __device__ int32_t tables_o0(uint32_t* cnt, uint2* ent, int32_t n_in, EncFixedLd
     }
     __syncthreads();
     int32_t len = 0;
-    if (l == 0) len = row_body<true>(cnt, 256, L->syml, tabdst);
+    if (l == 0) {
+        len = row_body<false>(cnt, 256, L->syml, nullptr);
+        if (len <= tab_cap) row_body<true>(cnt, 256, L->syml, tabdst);
+    }
     len = __shfl(len, 0);
     __syncthreads();
     return len;
@@ -512,7 +518,7 @@ __device__ __attribute__((noinline)) Res run_o0(Blk B) {
     for (int i = l; i < 256; i += 64) L->syml[i] = (uint8_t)i;
     __syncthreads();
     Res r;
-    r.tab_len = tables_o0(cnt0, ent0, B.n, L, B.slot + 9, B.rcp_tab);
+    r.tab_len = tables_o0(cnt0, ent0, B.n, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
     if (9 + r.tab_len + 16 > B.cap)
         r.pay_len = CRAMGPU_E_INSUFFICIENT;
     else
@@ -544,7 +550,7 @@ __device__ __attribute__((noinline)) Res run_o1_global(Blk B) {
         if (stop == 2) r.pay_len = -52;
     }
     if (r.pay_len == 0) {
-        r.tab_len = tables_o1(cnt, ent, 256, 256, 256, L, B.slot + 9, B.rcp_tab, B.dbg, stop);
+        r.tab_len = tables_o1(cnt, ent, 256, 256, 256, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16, B.dbg, stop);
         __threadfence();
         __syncthreads();
         if (r.tab_len < 0) r.pay_len = r.tab_len;
@@ -610,7 +616,7 @@ __device__ __attribute__((noinline)) Res run_o1_lds(Blk B) {
     for (int i = l; i < cells; i += 64) cnt[i] = 0;
     __syncthreads();
     hist_o1(B.src, B.n, cnt, stride, L->dmap, rep, R, rstride, cells);
-    r.tab_len = tables_o1(cnt, ent, ns, ns, stride, L, B.slot + 9, B.rcp_tab);
+    r.tab_len = tables_o1(cnt, ent, ns, ns, stride, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
     if (9 + r.tab_len + 16 > B.cap)
         r.pay_len = CRAMGPU_E_INSUFFICIENT;
     else

@@ -1,0 +1,301 @@
+"""Host-side mirror of the reference's record-level interfaces over flat containers, backed by libcramgpu (HIP only).
+
+Reference interface (SURVEY.md §8(b) level 2)                          -> here
+  htsjdk!build/Sam2CramRecordFactory#setRefBases / #createCramRecord     -> Sam2CramRecordFactory.set_ref_bases / create_variations
+  htsjdk!structure/SubstitutionMatrix#<init>([[J), #code                 -> substitution_matrix / assign_codes
+  CramNormalizer.restoreReadBases / restoreQualityScores (CramNormalizer.java:335-441, :287-333)
+                                                                         -> CramNormalizer.restore_read_bases / restore_quality_scores
+  QualityScorePreservation(spec).addQualityScores (QualityScorePreservation.java:139-301)
+                                                                         -> QualityScorePreservation(spec).add_quality_scores
+The object graph of the reference (SAMRecord, CramCompressionRecord, ReadFeature lists) is replaced by flat arrays
+(`ReadBatch`, `FeatureBatch`) because that is what crosses the JNI boundary; semantics and error behaviour follow the
+reference method by method.  Everything runs on the GPU; there is no CPU implementation in this package.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import CramGpuError, Features, Policy, Reads, RefWin
+
+RF_UNMAPPED, RF_NULL_QUALS, RF_NO_BASES = _lib.RF_UNMAPPED, _lib.RF_NULL_QUALS, _lib.RF_NO_BASES
+RF_UNKNOWN_BASES, RF_FORCE_QS, RF_SKIP = _lib.RF_UNKNOWN_BASES, _lib.RF_FORCE_QS, _lib.RF_SKIP
+DEFAULT_QUALITY_SCORE = 30  # '?' - '!' (CramNormalizer.java:141,204)
+
+_CIGAR_OPS = "MIDNSHP=X"
+
+
+def pack_cigar(text):
+    out, num = [], 0
+    for ch in text:
+        if ch.isdigit():
+            num = num * 10 + int(ch)
+        else:
+            out.append((num << 4) | _CIGAR_OPS.index(ch))
+            num = 0
+    return out
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _dev(x, dtype, device):
+    torch = _torch()
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(device)
+
+
+def _stream():
+    return _torch().cuda.current_stream().cuda_stream
+
+
+class ReadBatch:
+    """Reads of one or more containers as device arrays (the cramgpu_reads struct of include/cramgpu.h)."""
+
+    def __init__(self, device, bases, base_off, read_len, aln_start, cigar, cigar_off, n_cigar, quals=None, mapq=None,
+                 rflags=None, read_cont=None, windows=((0, 0, 0),)):
+        torch = _torch()
+        self.device = device
+        n = len(read_len)
+        self.n = n
+        self.bases = _dev(bases, torch.uint8, device)
+        self.quals = _dev(quals, torch.uint8, device) if quals is not None else torch.zeros_like(self.bases)
+        self.base_off = _dev(base_off, torch.int64, device)
+        self.read_len = _dev(read_len, torch.int32, device)
+        self.aln_start = _dev(aln_start, torch.int32, device)
+        self.cigar = _dev(cigar, torch.int32, device)  # bit pattern of uint32
+        self.cigar_off = _dev(cigar_off, torch.int64, device)
+        self.n_cigar = _dev(n_cigar, torch.int32, device)
+        self.mapq = _dev(mapq if mapq is not None else np.full(n, 60, np.uint8), torch.uint8, device)
+        self.rflags = _dev(rflags if rflags is not None else np.zeros(n, np.uint8), torch.uint8, device)
+        self.read_cont = _dev(read_cont, torch.int32, device) if read_cont is not None else None
+        w = np.asarray(windows, np.int64).reshape(-1, 3)  # (ref_off, ref_len, ref_start0) per container
+        self.n_cont = w.shape[0]
+        self.win = _dev(w.reshape(-1), torch.int64, device)
+        self.max_read_len = int(self.read_len.max().item()) if n else 0
+        self._keep = None
+
+    @staticmethod
+    def from_lists(device, starts, cigars, bases, quals=None, mapq=None, rflags=None, ref_len=0):
+        """Small batches from Python lists (tests): bases/quals are lists of bytes, cigars strings or packed lists."""
+        lens = [len(b) for b in bases]
+        off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64) if lens else np.zeros(0, np.int64)
+        packed = [pack_cigar(c) if isinstance(c, str) else list(c) for c in cigars]
+        nc = [len(c) for c in packed]
+        coff = np.concatenate([[0], np.cumsum(nc)[:-1]]).astype(np.int64) if nc else np.zeros(0, np.int64)
+        flat = np.asarray([x for c in packed for x in c] + [0], np.uint32).view(np.int32)
+        b = np.frombuffer(b"".join(bytes(x) for x in bases) + b"\0" * 16, np.uint8)
+        q = np.frombuffer(b"".join(bytes(x) for x in quals) + b"\0" * 16, np.uint8) if quals is not None else None
+        return ReadBatch(device, b, off, lens, starts, flat, coff, nc, quals=q, mapq=mapq, rflags=rflags,
+                         windows=((0, ref_len, 0),))
+
+    def struct(self):
+        r = Reads()
+        r.n_reads, r.n_cont = self.n, self.n_cont
+        r.n_bases, r.max_read_len = int(self.bases.numel()), self.max_read_len
+        r.bases, r.quals = self.bases.data_ptr(), self.quals.data_ptr()
+        r.base_off, r.read_len = self.base_off.data_ptr(), self.read_len.data_ptr()
+        r.aln_start, r.rflags, r.mapq = self.aln_start.data_ptr(), self.rflags.data_ptr(), self.mapq.data_ptr()
+        r.cigar, r.cigar_off, r.n_cigar = self.cigar.data_ptr(), self.cigar_off.data_ptr(), self.n_cigar.data_ptr()
+        r.read_cont = self.read_cont.data_ptr() if self.read_cont is not None else None
+        r.win = self.win.data_ptr()
+        return r
+
+
+class FeatureBatch:
+    """Flat read features on the device (cramgpu_features)."""
+
+    def __init__(self, device, n_reads, cap):
+        torch = _torch()
+        cap = max(int(cap), 1)
+        self.cap = cap
+        self.n_reads = n_reads
+        self.op = torch.zeros(cap, dtype=torch.uint8, device=device)
+        self.pos = torch.zeros(cap, dtype=torch.int32, device=device)
+        self.a = torch.zeros(cap, dtype=torch.int32, device=device)
+        self.b = torch.zeros(cap, dtype=torch.int32, device=device)
+        self.off = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
+        self.count = 0
+
+    @staticmethod
+    def from_host(device, op, pos, a, b, off):
+        f = FeatureBatch(device, len(off) - 1, len(op))
+        torch = _torch()
+        if len(op):
+            f.op[:len(op)] = torch.as_tensor(np.ascontiguousarray(op, np.uint8))
+            f.pos[:len(op)] = torch.as_tensor(np.ascontiguousarray(pos, np.int32))
+            f.a[:len(op)] = torch.as_tensor(np.ascontiguousarray(a, np.int32))
+            f.b[:len(op)] = torch.as_tensor(np.ascontiguousarray(b, np.int32))
+        f.off.copy_(torch.as_tensor(np.ascontiguousarray(off, np.int64)))
+        f.count = len(op)
+        return f
+
+    def struct(self):
+        s = Features()
+        s.op, s.pos, s.a, s.b, s.off = (self.op.data_ptr(), self.pos.data_ptr(), self.a.data_ptr(), self.b.data_ptr(),
+                                        self.off.data_ptr())
+        s.cap = self.cap
+        return s
+
+    def to_host(self):
+        n = self.count
+        return dict(op=self.op[:n].cpu().numpy(), pos=self.pos[:n].cpu().numpy(), a=self.a[:n].cpu().numpy(),
+                    b=self.b[:n].cpu().numpy(), off=self.off.cpu().numpy())
+
+
+def substitution_matrix(hist25):
+    """SubstitutionMatrix#<init>([[J): 25 counts ([ref][base] over ACGTN) -> 5 header bytes."""
+    h = np.ascontiguousarray(hist25, np.int64).reshape(-1)
+    assert h.size == 25
+    m = np.zeros(5, np.uint8)
+    _lib.lib().cramgpu_substitution_matrix(h.ctypes.data, m.ctypes.data)
+    return m
+
+
+class Sam2CramRecordFactory:
+    """htsjdk!build/Sam2CramRecordFactory: reference-diff read features for a batch of reads."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.ref = None
+
+    def set_ref_bases(self, d_ref):
+        """setRefBases(byte[]): the reference arena the batch's windows point into (device uint8 tensor)."""
+        self.ref = d_ref
+
+    def create_variations(self, reads, feature_cap=None, with_hist=True):
+        """createVariations for every read.  Returns (FeatureBatch, sub_hist[n_cont][25] on the host or None)."""
+        torch = _torch()
+        cap = feature_cap if feature_cap is not None else reads.n * 8 + 1024
+        while True:
+            feats = FeatureBatch(reads.device, reads.n, cap)
+            hist = torch.zeros(reads.n_cont * 25, dtype=torch.int64, device=reads.device) if with_hist else None
+            rs, fs = reads.struct(), feats.struct()
+            n = _lib.lib().cramgpu_extract_features_dev(self.engine.handle, C.byref(rs), self.ref.data_ptr(), C.byref(fs),
+                                                        hist.data_ptr() if with_hist else None, _stream())
+            if n == _lib.E_INSUFFICIENT:
+                cap = int(feats.off[-1].item()) + 16  # the scan already knows the exact need
+                continue
+            _lib.check(n)
+            feats.count = int(n)
+            torch.cuda.synchronize()
+            return feats, (hist.cpu().numpy().reshape(reads.n_cont, 25) if with_hist else None)
+
+    def assign_codes(self, reads, feats, matrices):
+        """Writer#write: code = matrix.code(refBase, base) for every Substitution feature."""
+        m = np.ascontiguousarray(matrices, np.uint8).reshape(-1)
+        fs = feats.struct()
+        _lib.check(_lib.lib().cramgpu_assign_codes_dev(
+            self.engine.handle, reads.n, reads.read_cont.data_ptr() if reads.read_cont is not None else None,
+            reads.n_cont, C.byref(fs), m.ctypes.data, _stream()))
+
+
+class CramNormalizer:
+    """src/main/java/htsjdk/samtools/cram/build/CramNormalizer.java: base and quality restoration (decode side)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def restore_read_bases(self, device, read_len, aln_start, rflags, feats, d_ref, windows, matrices, seq=None,
+                           seq_off=None, read_cont=None):
+        torch = _torch()
+        n = len(read_len)
+        rl = _dev(read_len, torch.int32, device)
+        st = _dev(aln_start, torch.int32, device)
+        fl = _dev(rflags, torch.uint8, device)
+        w = np.asarray(windows, np.int64).reshape(-1, 3)
+        d_win = _dev(w.reshape(-1), torch.int64, device)
+        out_off = torch.cumsum(rl.to(torch.int64), 0) - rl.to(torch.int64)
+        out = torch.zeros(int(rl.sum().item()) + 16, dtype=torch.uint8, device=device)
+        status = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+        d_seq = _dev(seq, torch.uint8, device) if seq is not None else torch.zeros(16, dtype=torch.uint8, device=device)
+        d_seq_off = _dev(seq_off, torch.int64, device) if seq_off is not None else torch.zeros(max(n, 1), dtype=torch.int64,
+                                                                                              device=device)
+        rc = _dev(read_cont, torch.int32, device) if read_cont is not None else None
+        m = np.ascontiguousarray(matrices, np.uint8).reshape(-1)
+        fs = feats.struct()
+        _lib.check(_lib.lib().cramgpu_restore_bases_dev(
+            self.engine.handle, n, rl.data_ptr(), st.data_ptr(), fl.data_ptr(), rc.data_ptr() if rc is not None else None,
+            w.shape[0], d_win.data_ptr(), C.byref(fs), d_seq.data_ptr(), d_seq_off.data_ptr(), d_ref.data_ptr(),
+            m.ctypes.data, out.data_ptr(), out_off.data_ptr(), status.data_ptr(), _stream()))
+        torch.cuda.synchronize()
+        return out, out_off, status[:n]
+
+    def restore_quality_scores(self, device, read_len, rflags, feats, scores, default_qs=DEFAULT_QUALITY_SCORE):
+        torch = _torch()
+        n = len(read_len)
+        rl = _dev(read_len, torch.int32, device)
+        fl = _dev(rflags, torch.uint8, device)
+        out_off = torch.cumsum(rl.to(torch.int64), 0) - rl.to(torch.int64)
+        sc = _dev(scores, torch.uint8, device).clone()
+        status = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+        fs = feats.struct()
+        _lib.check(_lib.lib().cramgpu_restore_quals_dev(self.engine.handle, n, rl.data_ptr(), fl.data_ptr(), C.byref(fs),
+                                                        int(default_qs), sc.data_ptr(), out_off.data_ptr(),
+                                                        status.data_ptr(), _stream()))
+        torch.cuda.synchronize()
+        return sc, status[:n]
+
+
+def parse_policies(spec):
+    """QualityScorePreservation.parsePolicies: spec -> ctypes Policy array sorted like the reference (host only)."""
+    arr = (Policy * 64)()
+    n = _lib.check(_lib.lib().cramgpu_parse_policies(spec.encode(), arr, 64))
+    return arr, n
+
+
+class QualityScorePreservation:
+    """src/main/java/htsjdk/samtools/cram/lossy/QualityScorePreservation.java (lossy quality model)."""
+
+    WINDOW = 1000000  # ReferenceTracks.java:23
+
+    def __init__(self, engine, spec):
+        self.engine = engine
+        self.spec = spec
+        self.policies, self.n_pol = parse_policies(spec)
+
+    def tracks_windows(self, aln_start, aln_span, rflags, mapq, ref_len, window=None):
+        """ReferenceTracks.ensureRange replayed in read order (host): window position per read."""
+        n = len(aln_start)
+        a = np.ascontiguousarray(aln_start, np.int32)
+        sp = np.ascontiguousarray(aln_span, np.int32)
+        fl = np.ascontiguousarray(rflags, np.uint8)
+        mq = np.ascontiguousarray(mapq, np.uint8)
+        wpos = np.zeros(max(n, 1), np.int32)
+        r = _lib.lib().cramgpu_tracks_windows(n, a.ctypes.data, sp.ctypes.data, fl.ctypes.data, mq.ctypes.data,
+                                              self.policies, self.n_pol, int(ref_len),
+                                              int(window if window is not None else self.WINDOW), wpos.ctypes.data)
+        if r < 0:
+            raise CramGpuError(_lib.E_JAVA_THROWS, "ReferenceTracks would throw at read %d" % (-r - 1))
+        return wpos[:n]
+
+    def add_quality_scores(self, reads, d_ref, wpos, window=None):
+        """addQualityScores for every read: (scores uint8 with 0xFF holes, force flags, status)."""
+        torch = _torch()
+        scores = torch.zeros(reads.bases.numel(), dtype=torch.uint8, device=reads.device)
+        force = torch.zeros(max(reads.n, 1), dtype=torch.uint8, device=reads.device)
+        status = torch.zeros(max(reads.n, 1), dtype=torch.int32, device=reads.device)
+        d_wpos = _dev(wpos, torch.int32, reads.device)
+        rs = reads.struct()
+        _lib.check(_lib.lib().cramgpu_lossy_quals_dev(self.engine.handle, C.byref(rs), d_ref.data_ptr(), d_wpos.data_ptr(),
+                                                      int(window if window is not None else self.WINDOW), self.policies,
+                                                      self.n_pol, scores.data_ptr(), force.data_ptr(), status.data_ptr(),
+                                                      _stream()))
+        torch.cuda.synchronize()
+        return scores, force[:reads.n], status[:reads.n]
+
+    def merge_quality_features(self, reads, scores, force, status, feats):
+        """Tail of addQualityScores: BaseQualityScore features for non-forced reads, stable-sorted by position."""
+        torch = _torch()
+        cap = feats.count + int(reads.bases.numel()) + 16
+        out = FeatureBatch(reads.device, reads.n, cap)
+        fi, fo = feats.struct(), out.struct()
+        n = _lib.check(_lib.lib().cramgpu_merge_quality_features_dev(
+            self.engine.handle, reads.n, reads.read_len.data_ptr(), reads.base_off.data_ptr(), scores.data_ptr(),
+            force.data_ptr(), status.data_ptr(), C.byref(fi), C.byref(fo), _stream()))
+        out.count = int(n)
+        torch.cuda.synchronize()
+        return out
