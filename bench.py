@@ -1,0 +1,312 @@
+#!/usr/bin/env python
+"""bench.py — CRAM encode hot path on MI355X (BASELINE.json configs[1]).
+
+One "step" = one pass of the encode hot path over the whole synthetic read set resident in HBM:
+  K3  reference-diff feature extraction over every read (two passes + scan, substitution histogram),
+  F3  substitution matrices (host, 25 numbers per container) + code assignment,
+  K1  rANS order-0 / order-1 encode of every external block of every container (QS, BA, BF, CF, NS, RG, RL, TS
+      order 1; AP, RI order 0 — the fixed series->codec map of CompressionHeaderFactory#build L82-124),
+  gather of the compressed streams into one dense arena (what would cross PCIe).
+Workload: 10M x 150 bp Illumina-like reads vs a 64 Mbp synthetic reference, 1000 containers of 10 000 reads,
+lossless qualities.  The external-block byte streams are synthesised on the device once (untimed): the data-series
+writer that produces them in the reference (Writer#write) is a "next" row of SURVEY.md §8(f), not part of this path.
+
+Contract: python bench.py --gpus N --steps K --warmup W ; N > 1 under torch.distributed.run, one rank per GPU, each
+rank codes its own shard of the same size (weak scaling; containers are independent, no collective on the data path).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from cramtools_amd import _lib, synth_torch
+from cramtools_amd import external_compression as xc
+from cramtools_amd import records as rec
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+READS_PER_CONTAINER = 10000  # CramContext.java:33
+# series of the block corpus: (name, rANS order) — CompressionHeaderFactory#build L82-124
+SERIES = [("QS", 1), ("AP", 0), ("RI", 0), ("BA", 1), ("BF", 1), ("CF", 1), ("NS", 1), ("RG", 1), ("RL", 1), ("TS", 1)]
+
+
+def gpu_insert_bases(eng, reads, ref, n_reads):
+    """(is-InsertBase mask, payload, per-read feature offsets) of one K3 run — used to lay out the BA series."""
+    fac = rec.Sam2CramRecordFactory(eng)
+    fac.set_ref_bases(ref)
+    feats, _ = fac.create_variations(reads, feature_cap=n_reads * 2 + 1024, with_hist=False)
+    n = feats.count
+    return feats.op[:n].clone(), feats.a[:n].clone(), feats.off.clone()
+
+
+def build_workload(dev, n_reads, ref_len, read_len, seed_shift, features_of):
+    """Reads + reference + the per-container external-block corpus, all on `dev`.
+    features_of(reads, ref) -> (op, a, off) of the reads' features (the GPU kernel in the bench, the oracle in tests)."""
+    ref = synth_torch.reference(ref_len, device=dev)
+    ref = torch.cat([ref, torch.zeros(16, dtype=torch.uint8, device=dev)])
+    rs = synth_torch.make_reads(n_reads, ref[:ref_len], read_len=read_len, seed=1 + seed_shift, qual_seed=2 + seed_shift,
+                                err_seed=3 + seed_shift)
+    n_cont = (n_reads + READS_PER_CONTAINER - 1) // READS_PER_CONTAINER
+    read_cont = (torch.arange(n_reads, device=dev) // READS_PER_CONTAINER).to(torch.int32)
+    reads = rec.ReadBatch(dev, rs.bases, rs.base_off, rs.read_len, rs.aln_start, rs.cigar, rs.cigar_off, rs.n_cigar,
+                          quals=rs.quals, mapq=rs.mapq, rflags=rs.rflags, read_cont=read_cont,
+                          windows=[(0, ref_len, 0)] * n_cont)
+    # ---- value series of the records (synthetic but shaped like the reference's) ----
+    fr = rs.flags_rnd
+    cont_first = torch.arange(n_cont, device=dev) * READS_PER_CONTAINER
+    starts = rs.aln_start.to(torch.int64)
+    ap = starts.clone()
+    ap[1:] = starts[1:] - starts[:-1]
+    ap[cont_first] = starts[cont_first] - starts[cont_first]  # AP delta restarts at 0 in every container (slice start)
+    bf = torch.tensor([99, 147, 83, 163], device=dev)[(fr >> 9) % 4]  # paired, proper, strand/mate bits
+    cf = torch.full((n_reads,), 3, device=dev)  # force-preserve QS | detached
+    ri = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    ns = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    rg = torch.full((n_reads,), -1, device=dev)
+    rl = rs.read_len.to(torch.int64)
+    ts = (300 + ((fr >> 11) % 101) - 50) * torch.where(((fr >> 9) & 1) == 0, 1, -1)
+    series_bytes = {}
+    for name, vals in (("AP", ap), ("RI", ri), ("BF", bf), ("CF", cf), ("NS", ns), ("RG", rg), ("RL", rl), ("TS", ts)):
+        b, off = synth_torch.itf8(vals)
+        series_bytes[name] = (b, off[cont_first], torch.cat([off[cont_first[1:]], off[-1:]]))
+    # QS: with lossless qualities every record carries its quality array (Writer#write L139-261)
+    q_lo = rs.base_off[cont_first]
+    q_hi = torch.cat([q_lo[1:], torch.tensor([n_reads * read_len], device=dev)])
+    series_bytes["QS"] = (rs.quals, q_lo, q_hi)
+    # BA: bases of InsertBase features, in record order (one K3 run at set-up time)
+    f_op, f_a, f_off = features_of(reads, ref)
+    n_feat = int(f_op.numel())
+    is_i = f_op == ord("i")
+    ba = f_a[is_i].to(torch.uint8)
+    ci = torch.zeros(n_feat + 1, dtype=torch.int64, device=dev)
+    ci[1:] = torch.cumsum(is_i.to(torch.int64), 0)
+    f_lo = f_off[cont_first]
+    f_hi = torch.cat([f_off[cont_first[1:]], f_off[-1:]])
+    series_bytes["BA"] = (torch.cat([ba, torch.zeros(16, dtype=torch.uint8, device=dev)]), ci[f_lo], ci[f_hi])
+    feat_cap = n_feat + 1024
+    del f_op, f_a, f_off
+    # ---- pack every (container, series) piece at 16-byte aligned offsets of one input arena ----
+    lens = torch.stack([series_bytes[name][2] - series_bytes[name][1] for name, _ in SERIES], 1)  # [n_cont, n_series]
+    lens_h = lens.cpu().numpy().astype(np.int64)
+    orders = np.tile(np.array([o for _, o in SERIES], np.int32), n_cont)
+    flat_len = lens_h.reshape(-1)
+    blocks, in_bytes, out_bytes = xc.Engine.plan_encode(flat_len, orders)
+    n_blocks = flat_len.size
+    d_in = torch.zeros(in_bytes, dtype=torch.uint8, device=dev)
+    in_off = np.array([blocks[i].in_off for i in range(n_blocks)], np.int64).reshape(n_cont, len(SERIES))
+    for k, (name, _) in enumerate(SERIES):
+        src, lo, hi = series_bytes[name]
+        total = int((hi - lo).sum().item())
+        if total == 0:
+            continue
+        # piece c copies src[lo[c]:hi[c]] to d_in[in_off[c,k]:...]: one flat index gather per series
+        ln = (hi - lo)
+        if total > (256 << 20):  # large pieces (QS): one plain copy per container
+            lo_h, hi_h = lo.cpu().numpy(), hi.cpu().numpy()
+            for c in range(n_cont):
+                d_in[in_off[c, k]:in_off[c, k] + int(hi_h[c] - lo_h[c])] = src[int(lo_h[c]):int(hi_h[c])]
+            continue
+        dst0 = torch.as_tensor(in_off[:, k], device=dev)
+        rep = torch.repeat_interleave(torch.arange(n_cont, device=dev), ln)
+        within = torch.arange(total, device=dev) - torch.repeat_interleave(torch.cumsum(ln, 0) - ln, ln)
+        d_in[dst0[rep] + within] = src[lo[rep] + within]
+        del rep, within
+    return dict(ref=ref, reads=reads, rs=rs, n_cont=n_cont, blocks=blocks, n_blocks=n_blocks, d_in=d_in,
+                out_bytes=out_bytes, raw_bytes=int(flat_len.sum()), feat_cap=feat_cap, lens=lens_h, max_cap=max(
+                    blocks[i].out_cap for i in range(n_blocks)))
+
+
+class Step:
+    """Pre-allocated device state of one encode step (nothing is allocated inside the timed region)."""
+
+    def __init__(self, dev, eng, w):
+        self.dev, self.eng, self.w = dev, eng, w
+        n = w["n_blocks"]
+        self.d_out = torch.empty(w["out_bytes"], dtype=torch.uint8, device=dev)
+        self.d_len = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.d_pos = torch.zeros(n, dtype=torch.int64, device=dev)
+        self.d_pack = torch.empty(w["raw_bytes"] + 32 * n + (64 << 20), dtype=torch.uint8, device=dev)
+        self.d_pack_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        self.feats = rec.FeatureBatch(dev, w["reads"].n, w["feat_cap"])
+        self.hist = torch.zeros(w["n_cont"] * 25, dtype=torch.int64, device=dev)
+        self.fac = rec.Sam2CramRecordFactory(eng)
+        self.fac.set_ref_bases(w["ref"])
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self.enc_ms = []
+
+    def run(self, timed):
+        w, L = self.w, _lib.lib()
+        reads = w["reads"]
+        s = torch.cuda.current_stream().cuda_stream
+        # K3 + F3
+        self.hist.zero_()
+        rs_, fs_ = reads.struct(), self.feats.struct()
+        n = _lib.check(L.cramgpu_extract_features_dev(self.eng.handle, C.byref(rs_), w["ref"].data_ptr(), C.byref(fs_),
+                                                      self.hist.data_ptr(), s))
+        self.feats.count = int(n)
+        hist = self.hist.cpu().numpy().reshape(w["n_cont"], 25)
+        mats = np.zeros((w["n_cont"], 5), np.uint8)
+        for c in range(w["n_cont"]):
+            L.cramgpu_substitution_matrix(hist[c].ctypes.data, mats[c].ctypes.data)
+        self.fac.assign_codes(reads, self.feats, mats)
+        # K1 + gather
+        if timed:
+            self.ev[0].record()
+        self.eng.encode_dev(w["d_in"], self.d_out, w["blocks"], w["n_blocks"], self.d_len, self.d_pos)
+        if timed:
+            self.ev[1].record()
+        self.eng.gather_dev(self.d_out, self.d_pos, self.d_len, w["n_blocks"], w["max_cap"], self.d_pack, self.d_pack_off)
+        if timed:
+            torch.cuda.synchronize()
+            self.enc_ms.append(self.ev[0].elapsed_time(self.ev[1]))
+
+
+def cpu_baseline(w, budget_s=15.0):
+    """The CPU oracle (C restatement of htsjdk 2.4.1 rANS, oracle/rans4x8.c) on a bounded sample of the same blocks."""
+    from oracle import orc
+    orc.build()
+    L = orc.lib()
+    cores = min(16, os.cpu_count() or 1)
+    n_series = len(SERIES)
+    blocks, d_in = w["blocks"], w["d_in"]
+    # pilot on one container to size the sample
+    def take(c0, c1):
+        lo = blocks[c0 * n_series].in_off
+        last = blocks[c1 * n_series - 1]
+        hi = last.in_off + last.in_len
+        arena = d_in[lo:hi].cpu().numpy()
+        off = np.array([blocks[i].in_off - lo for i in range(c0 * n_series, c1 * n_series)], np.int64)
+        ln = np.array([blocks[i].in_len for i in range(c0 * n_series, c1 * n_series)], np.int32)
+        od = np.array([blocks[i].order for i in range(c0 * n_series, c1 * n_series)], np.int32)
+        return arena, off, ln, od
+
+    def run(arena, off, ln, od, threads):
+        caps = np.array([orc.rans_bound(int(x)) for x in ln], np.int64)
+        ooff = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.int64)
+        out = np.empty(int(caps.sum()) + 16, np.uint8)
+        olen = np.zeros(ln.size, np.int32)
+        idx = [np.arange(t, ln.size // n_series, threads) for t in range(threads)]  # containers round-robin
+        def work(cs):
+            for c in cs:
+                s = slice(c * n_series, (c + 1) * n_series)
+                o, l2, d2, oo = (np.ascontiguousarray(off[s]), np.ascontiguousarray(ln[s]), np.ascontiguousarray(od[s]),
+                                 np.ascontiguousarray(ooff[s]))
+                ol = np.zeros(n_series, np.int32)
+                r = L.orc_rans_compress_many(arena.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p),
+                                             l2.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p), C.c_int32(n_series),
+                                             out.ctypes.data_as(C.c_void_p), oo.ctypes.data_as(C.c_void_p),
+                                             ol.ctypes.data_as(C.c_void_p))
+                assert r >= 0
+                olen[s] = ol
+        ths = [threading.Thread(target=work, args=(i,)) for i in idx]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return time.perf_counter() - t0, out, ooff, olen
+
+    a, o, l, d = take(0, 1)
+    t1, _, _, _ = run(a, o, l, d, 1)
+    per_cont = max(t1, 1e-4)
+    n_c = int(min(w["n_cont"], max(cores, budget_s * cores / per_cont)))
+    n_c = max(cores, n_c - n_c % cores) if w["n_cont"] >= cores else w["n_cont"]
+    n_c = min(n_c, w["n_cont"])
+    a, o, l, d = take(0, n_c)
+    dt, out, ooff, olen = run(a, o, l, d, min(cores, n_c))
+    mb = float(l.sum()) / 1e6
+    return dict(value=mb / dt, unit="MB/s", cores=min(cores, n_c), kind="port",
+                sample="oracle/rans4x8.c (C restatement of htsjdk 2.4.1 RANS, not the JVM) on the first %d containers "
+                       "(%d blocks, %.1f MB raw), one container per thread at a time" % (n_c, l.size, mb)), (out, ooff, olen, n_c)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--ref-len", type=int, default=64_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    eng = xc.Engine(local)
+
+    w = build_workload(dev, a.reads, a.ref_len, a.read_len, 10 * rank,
+                       lambda reads, ref: gpu_insert_bases(eng, reads, ref, a.reads))
+    step = Step(dev, eng, w)
+    for _ in range(a.warmup):
+        step.run(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step.run(True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # parity verdict on this rank's blocks: no negative lengths, and the sampled containers equal the CPU oracle
+    lens = step.d_len.cpu().numpy()
+    assert (lens >= 0).all(), "a block failed to encode: %r" % (lens[lens < 0][:8],)
+    comp_bytes = int(lens[lens > 0].sum())
+    extra = {}
+    if rank == 0:
+        if not a.no_cpu_baseline:
+            base, (out, ooff, olen, n_c) = cpu_baseline(w)
+            extra["cpu_baseline"] = base
+            ns = len(SERIES)
+            pos = step.d_pos.cpu().numpy()
+            for i in range(n_c * ns):
+                got = step.d_out[int(pos[i]):int(pos[i]) + int(lens[i])].cpu().numpy()
+                assert int(lens[i]) == int(olen[i]) and np.array_equal(got, out[ooff[i]:ooff[i] + olen[i]]), \
+                    "block %d differs from the oracle" % i
+            extra["parity"] = "first %d blocks byte-identical to the CPU oracle" % (n_c * ns)
+        enc_s = float(np.mean(step.enc_ms)) / 1e3
+        algo = w["raw_bytes"] + comp_bytes  # n_raw + n_comp per encoded block
+        ach = algo / enc_s / 1e9
+        extra["roofline"] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                                 traffic=None, kernel="rans_encode_kernel", ms_per_launch=enc_s * 1e3)
+        total_raw = w["raw_bytes"] * world
+        line = dict(metric="CRAM encode hot path: uncompressed external-block payload MB/s (rANS o0/o1 + feature extraction)",
+                    value=total_raw * a.steps / dt / 1e6, unit="MB/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                    ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8",
+                    data="synthetic",
+                    config=dict(workload="configs[1]: %d x %d bp reads vs %d bp reference, %d containers x %d rANS blocks, lossless"
+                                % (a.reads, a.read_len, a.ref_len, w["n_cont"], len(SERIES)), reads_per_gpu=a.reads,
+                                parallelism="containers sharded by index, %d rank(s), no collective" % world),
+                    reads_per_s=a.reads * world * a.steps / dt, compression_ratio=w["raw_bytes"] / max(comp_bytes, 1))
+        line.update(extra)
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
