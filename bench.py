@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-from cramtools_amd import _lib, synth_torch
+from cramtools_amd import _lib, sharding, synth_torch
 from cramtools_amd import external_compression as xc
 from cramtools_amd import records as rec
 
@@ -257,19 +257,9 @@ def main():
     step = Step(dev, eng, w)
     for _ in range(a.warmup):
         step.run(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step.run(True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # barrier + synchronize on both sides of exactly `steps` steps, MAX over ranks (cramtools_amd/sharding.py)
+    dt = sharding.timed_region(lambda: step.run(True), a.steps, dist=dist if world > 1 else None,
+                               sync=torch.cuda.synchronize)
 
     # parity verdict on this rank's blocks: no negative lengths, and the sampled containers equal the CPU oracle
     lens = step.d_len.cpu().numpy()
