@@ -25,6 +25,14 @@
     } while (0)
 #endif
 
+// Lanes of a wave execute in lock step on the GPU, so "lane A reads LDS, then (later in program order) lane B
+// overwrites it" needs nothing there; the host harness runs lanes as free threads and needs a rendezvous.
+#ifdef HIP_SIM
+#define CRAMGPU_LOCKSTEP() __builtin_amdgcn_wave_barrier()
+#else
+#define CRAMGPU_LOCKSTEP() ((void)0)
+#endif
+
 #define RANS_TF_SHIFT 12
 #define RANS_TOTFREQ 4096
 #define RANS_BYTE_L (1u << 23)

@@ -28,12 +28,18 @@ namespace {
 constexpr int kSteps = 16;  // steps per batch: 16 steps x 4 states = 64 lanes
 
 struct EncFixedLds {
-    uint4 stageA[64];     // x_max, x_max<<8 (saturated), rcp_freq, bias
-    uint2 stageB[64];     // cmpl_freq, rcp_shift-32
-    uint32_t xs[64];      // state of (step, lane) before the step
-    uint32_t rowT[256];   // order-1 row totals (0 = context absent)
-    uint32_t rowoff[256]; // serialised length of each row
-    uint32_t rowhdr[256]; // context-level header of each row: count | byte0 << 8 | byte1 << 16
+    union {
+        struct {                    // phase 2 (tables)
+            uint32_t rowT[256];     // order-1 row totals (0 = context absent)
+            uint32_t rowoff[256];   // serialised length of each row
+            uint32_t rowhdr[256];   // context-level header of each row: count | byte0 << 8 | byte1 << 16
+        } p2;
+        struct {                    // phase 3 (coding loop)
+            uint4 stageA[2][64];    // x_max, x_max<<8 (saturated), rcp_freq, bias     (double buffered)
+            uint2 stageB[2][64];    // cmpl_freq, rcp_shift-32
+            uint32_t xs[kSteps][64];  // state of every lane before each step of the current batch
+        } p3;
+    };
     uint8_t dmap[256];    // byte value -> dense index
     uint8_t syml[256];    // dense index -> byte value
 };
@@ -235,7 +241,7 @@ __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent
         uint32_t* c = cnt + row * stride;
         uint32_t T = 0;
         for (int j = 0; j < n; j++) T += c[j];
-        L->rowT[row] = T;
+        L->p2.rowT[row] = T;
         if (T == 0) continue;
         const double p = 4096.0 / (double)(int32_t)T;
         int32_t m = 0, M = 0, t2 = 0;
@@ -265,24 +271,24 @@ __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent
         const int row = l * rpl + k;
         if (row >= nrows) break;
         uint32_t len = 0, hdr = 0;
-        if (L->rowT[row] != 0) {
+        if (L->p2.rowT[row] != 0) {
             const int v = L->syml[row];
-            const bool link = v > 0 && row > 0 && L->syml[row - 1] == v - 1 && L->rowT[row - 1] != 0;
+            const bool link = v > 0 && row > 0 && L->syml[row - 1] == v - 1 && L->p2.rowT[row - 1] != 0;
             if (!link) {
                 hdr = 1u | ((uint32_t)v << 8);
             } else {
                 const int pv = v - 1;
-                const bool plink = pv > 0 && row > 1 && L->syml[row - 2] == pv - 1 && L->rowT[row - 2] != 0;
+                const bool plink = pv > 0 && row > 1 && L->syml[row - 2] == pv - 1 && L->p2.rowT[row - 2] != 0;
                 if (!plink) {
                     int kk = row + 1;
-                    while (kk < nrows && L->syml[kk] == L->syml[kk - 1] + 1 && L->rowT[kk] != 0) kk++;
+                    while (kk < nrows && L->syml[kk] == L->syml[kk - 1] + 1 && L->p2.rowT[kk] != 0) kk++;
                     hdr = 2u | ((uint32_t)v << 8) | ((uint32_t)(kk - (row + 1)) << 16);
                 }
             }
             len = (hdr & 3u) + (uint32_t)row_body<false>(cnt + row * stride, n, L->syml, nullptr);
         }
-        L->rowoff[row] = len;
-        L->rowhdr[row] = hdr;
+        L->p2.rowoff[row] = len;
+        L->p2.rowhdr[row] = hdr;
         mylen += len;
     }
     uint32_t total;
@@ -300,9 +306,9 @@ __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent
     for (int k = 0; k < rpl; k++) {
         const int row = l * rpl + k;
         if (row >= nrows) break;
-        const uint32_t len = L->rowoff[row];
+        const uint32_t len = L->p2.rowoff[row];
         if (len != 0 && base + len <= total) {
-            const uint32_t hdr = L->rowhdr[row];
+            const uint32_t hdr = L->p2.rowhdr[row];
             uint8_t* d = tabdst + base;
             if ((hdr & 3u) >= 1) d[0] = (uint8_t)(hdr >> 8);
             if ((hdr & 3u) == 2) d[1] = (uint8_t)(hdr >> 16);
@@ -319,7 +325,7 @@ __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent
     for (int k = 0; k < rpl; k++) {
         int row = l * rpl + k;
         if (row >= nrows) break;
-        if (L->rowT[row] == 0) continue;
+        if (L->p2.rowT[row] == 0) continue;
         const uint32_t* c = cnt + row * stride;
         uint2* e = ent + row * stride;
         uint32_t C = 0;
@@ -398,12 +404,71 @@ __device__ int32_t tables_o0(uint32_t* cnt, uint2* ent, int32_t n_in, EncFixedLd
 // ---------------------------------------------------------------------------------------------------------
 enum { MODE_O0 = 0, MODE_O1_LDS = 1, MODE_O1_GLOBAL = 2 };
 
+// The bytes one lane prepares for a batch: lane (t, j) owns step ub + t of state j.
+struct Fetch {
+    uint32_t sym, ctx;
+    bool act;
+};
+
+template <int MODE>
+__device__ __forceinline__ Fetch fetch_batch(const uint8_t* src, int32_t n, int32_t q, int32_t rem, int32_t U, int32_t ub,
+                                             int t, int j) {
+    Fetch f{0u, 0u, false};
+    const int32_t u = ub + t;
+    bool act = u < U;
+    int32_t pos = 0;
+    if (MODE == MODE_O0) {
+        pos = (n & ~3) - 4 * u + j;
+        act = act && pos < n;  // u == 0: only states j < (n&3)
+    } else {
+        int32_t k;
+        if (j == 3) {
+            k = U - 1 - u;
+            pos = 3 * q + k;
+        } else {
+            k = q - 1 - (u - rem);
+            pos = j * q + k;
+            act = act && u >= rem;
+        }
+        if (act && k > 0) f.ctx = src[pos - 1];  // k == 0: the quarter's first symbol is coded in context 0
+    }
+    if (act) f.sym = src[pos];
+    f.act = act;
+    return f;
+}
+
+template <int MODE>
+__device__ __forceinline__ void stage_batch(const Fetch& f, const uint2* ent, int stride, EncFixedLds* L, int buf, int slot,
+                                            uint4& A) {
+    A = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);  // identity step for inactive (step, state) pairs
+    uint2 B = make_uint2(0u, 0u);
+    if (f.act) {
+        uint2 e;
+        if (MODE == MODE_O0)
+            e = ent[f.sym];
+        else if (MODE == MODE_O1_LDS)
+            e = ent[(uint32_t)L->dmap[f.ctx] * (uint32_t)stride + L->dmap[f.sym]];
+        else
+            e = ent[f.ctx * 256u + f.sym];
+        expand_symbol(e, A, B);
+    }
+    L->p3.stageA[buf][slot] = A;
+    L->p3.stageB[buf][slot] = B;
+}
+
 // Returns payload length (including the 16 state bytes) or a negative code.  Payload is written downwards from pend.
+// Software pipeline over batches of 16 steps, all in one loop body so that the scheduler can fill the latency gaps of
+// the serial chain: iteration i  (a) stages batch i+1 (symbol lookup + expansion, from bytes fetched one iteration
+// earlier) and fetches the bytes of batch i+2,  (b) runs the 16 chain steps of batch i,  (c) turns the logged states
+// of batch i-1 into output bytes.  The chain is executed by ALL lanes (lane l replicates state l&3): that costs
+// nothing on a SIMD and keeps EXEC constant, which is what lets (a) and (c) interleave with (b).
 template <int MODE>
 __device__ int32_t encode_stream(const uint8_t* src, int32_t n, const uint2* ent, int stride, EncFixedLds* L,
                                  uint8_t* pend, int32_t room, uint32_t* dbg = nullptr) {
+    (void)dbg;
     const int l = lane_id();
-    const int t = l >> 2, j = 3 - (l & 3);
+    const int t = l >> 2, j = 3 - (l & 3), sl = l & 3;
+    const int slot = t * 4 + j;
     const int32_t q = n >> 2;
     int32_t U, rem = 0;
     if (MODE == MODE_O0) {
@@ -412,68 +477,64 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n, const uint2* ent
         rem = n - 4 * q;  // state 3 codes the remainder alone first (E14 L27-31)
         U = q + rem;
     }
+    const int32_t nbatch = (U + kSteps - 1) / kSteps;
     uint32_t x = RANS_BYTE_L;
     int32_t run = 0;
     const int32_t limit = room - 16;
-    for (int32_t ub = 0; ub < U; ub += kSteps) {
-        if (l == 0) CRAMGPU_MARK(dbg, 3, 0x1000 + ub);
-        const int32_t u = ub + t;
-        bool act = u < U;
-        int32_t pos = 0;
-        uint32_t ctx = 0;
-        if (MODE == MODE_O0) {
-            pos = (n & ~3) - 4 * u + j;
-            act = act && pos < n;  // u == 0: only states j < (n&3)
-        } else {
-            int32_t k;
-            if (j == 3) {
-                k = U - 1 - u;
-                pos = 3 * q + k;
-            } else {
-                k = q - 1 - (u - rem);
-                pos = j * q + k;
-                act = act && u >= rem;
-            }
-            if (act && k > 0) ctx = src[pos - 1];  // k == 0: the quarter's first symbol is coded in context 0
-        }
-        uint4 A = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);  // identity step for inactive (step, state) pairs
-        uint2 B = make_uint2(0u, 0u);
-        if (act) {
-            const uint32_t sym = src[pos];
-            uint2 e;
-            if (MODE == MODE_O0)
-                e = ent[sym];
-            else if (MODE == MODE_O1_LDS)
-                e = ent[(uint32_t)L->dmap[ctx] * (uint32_t)stride + L->dmap[sym]];
-            else
-                e = ent[ctx * 256u + sym];
-            expand_symbol(e, A, B);
-        }
-        L->stageA[t * 4 + j] = A;
-        L->stageB[t * 4 + j] = B;
-        __syncthreads();
-        if (l == 0) CRAMGPU_MARK(dbg, 3, 0x2000 + ub);
-        if (l < 4) {
+    uint4 A, prevA = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+    Fetch f = fetch_batch<MODE>(src, n, q, rem, U, 0, t, j);
+    stage_batch<MODE>(f, ent, stride, L, 0, slot, A);
+    f = fetch_batch<MODE>(src, n, q, rem, U, kSteps, t, j);
+    __syncthreads();
+    for (int32_t i = 0; i < nbatch; i++) {
+        const int buf = i & 1;
+        // (c) states logged by the previous batch (read before this batch overwrites the log)
+        const uint32_t xv = L->p3.xs[t][3 - (l & 3)];
+        CRAMGPU_LOCKSTEP();
+        // (a) stage batch i+1, fetch batch i+2
+        uint4 An;
+        stage_batch<MODE>(f, ent, stride, L, buf ^ 1, slot, An);
+        f = fetch_batch<MODE>(src, n, q, rem, U, (i + 2) * kSteps, t, j);
+        // (b) Encoding#RansEncPutSymbol L46-71, 16 steps
+        // all 16 staged symbols go to registers first so that no LDS latency sits between two chain steps
+        uint4 sa[kSteps];
+        uint2 sb[kSteps];
 #pragma unroll
-            for (int tt = 0; tt < kSteps; tt++) {
-                const uint4 a = L->stageA[tt * 4 + l];
-                const uint2 b = L->stageB[tt * 4 + l];
-                L->xs[tt * 4 + l] = x;
-                // Encoding#RansEncPutSymbol L46-71
-                uint32_t sh = (x >= a.x ? 8u : 0u) + (x >= a.y ? 8u : 0u);
-                uint32_t xr = x >> sh;
-                uint32_t qq = __umulhi(xr, a.z) >> b.y;
-                x = xr + a.w + qq * b.x;
-            }
+        for (int tt = 0; tt < kSteps; tt++) {
+            sa[tt] = L->p3.stageA[buf][tt * 4 + sl];
+            sb[tt] = L->p3.stageB[buf][tt * 4 + sl];
         }
+#pragma unroll
+        for (int tt = 0; tt < kSteps; tt++) {
+            L->p3.xs[tt][l] = x;
+            const bool r1 = x >= sa[tt].x, r2 = x >= sa[tt].y;  // two independent compares, then two selects
+            const uint32_t sh = r2 ? 16u : (r1 ? 8u : 0u);
+            const uint32_t xr = x >> sh;
+            const uint32_t qq = __umulhi(xr, sa[tt].z) >> sb[tt].y;  // qq < 2^19, cmpl_freq < 2^12: 24-bit multiply is exact
+            x = __umul24(qq, sb[tt].x) + (xr + sa[tt].w);
+        }
+        // (c) bytes of batch i-1 in the reference's emission order (state 3,2,1,0 per step = lane order)
+        if (i > 0) {
+            const int nb = (xv >= prevA.x ? 1 : 0) + (xv >= prevA.y ? 1 : 0);
+            const unsigned long long m1 = __ballot(nb >= 1), m2 = __ballot(nb == 2);
+            const int32_t tot = __popcll(m1) + __popcll(m2);
+            if (run + tot > limit) return CRAMGPU_E_INSUFFICIENT;
+            const int32_t idx = run + (int32_t)(mbcnt(m1) + mbcnt(m2));
+            if (nb >= 1) pend[-1 - idx] = (uint8_t)xv;
+            if (nb == 2) pend[-2 - idx] = (uint8_t)(xv >> 8);
+            run += tot;
+        }
+        prevA = A;
+        A = An;
         __syncthreads();
-        const uint32_t xv = L->xs[t * 4 + j];
-        const int nb = (xv >= A.x ? 1 : 0) + (xv >= A.y ? 1 : 0);
+    }
+    if (nbatch > 0) {
+        const uint32_t xv = L->p3.xs[t][3 - (l & 3)];
+        const int nb = (xv >= prevA.x ? 1 : 0) + (xv >= prevA.y ? 1 : 0);
         const unsigned long long m1 = __ballot(nb >= 1), m2 = __ballot(nb == 2);
         const int32_t tot = __popcll(m1) + __popcll(m2);
         if (run + tot > limit) return CRAMGPU_E_INSUFFICIENT;
         const int32_t idx = run + (int32_t)(mbcnt(m1) + mbcnt(m2));
-        if (l == 0) CRAMGPU_MARK(dbg, 3, 0x3000 + ub);
         if (nb >= 1) pend[-1 - idx] = (uint8_t)xv;
         if (nb == 2) pend[-2 - idx] = (uint8_t)(xv >> 8);
         run += tot;

@@ -139,6 +139,7 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
 inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 inline uint32_t __builtin_amdgcn_mbcnt_lo(uint32_t m, uint32_t base) {
     int l = hipsim::lane();
     uint32_t lt = l >= 32 ? 0xFFFFFFFFu : ((1u << l) - 1);
