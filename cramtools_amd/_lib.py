@@ -113,6 +113,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libcramgpu.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                "cramtools_amd has no CPU fallback")
+        # torch ships its own libamdhip64 (same soname as /opt/rocm's).  It has to be in the process BEFORE libcramgpu
+        # is loaded so that both resolve to ONE HIP runtime: two runtimes in a process cannot share device pointers,
+        # and the second one to initialise sees no GPU.  Hosts without torch (the JNI path) use /opt/rocm's.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

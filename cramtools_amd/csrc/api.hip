@@ -120,7 +120,9 @@ namespace {
 
 constexpr int kTicketSlots = 256;
 
-hipStream_t pick(cramgpu_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+// NULL is HIP's own null stream (what torch calls the default stream), NOT the context's private stream: work the
+// caller queued on the null stream before the call is ordered before ours.
+hipStream_t pick(cramgpu_ctx*, void* stream) { return (hipStream_t)stream; }
 
 // uploads descriptors + LPT permutation, returns device pointers valid in stream order
 int stage_blocks(cramgpu_ctx* c, const cramgpu_block* blocks, int32_t n, hipStream_t s, bool encode) {

@@ -9,7 +9,7 @@
  * Conventions
  *   - plain pointers and sizes only; no C++/torch types.
  *   - "host" pointers are ordinary process memory; "dev" pointers are HIP device memory on the context's GPU.
- *   - stream arguments are hipStream_t passed as void* (NULL = the context's own stream).
+ *   - stream arguments are hipStream_t passed as void* (NULL = HIP's null stream, i.e. torch's default stream).
  *   - functions return >= 0 on success and a negative CRAMGPU_E_* code on failure; per-block results of
  *     batch calls carry the same codes in out_len[].
  *   - all functions are thread-safe on distinct contexts; one context serialises its calls internally.
