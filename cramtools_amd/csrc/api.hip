@@ -108,12 +108,12 @@ struct cramgpu_ctx {
     PinBuf<int64_t> h_off;
     // record kernels
     DevBuf<int32_t> d_counts;
-    DevBuf<int64_t> d_total;
+    DevBuf<int64_t> d_total, d_scan_ws;
     PinBuf<int64_t> h_total;
     DevBuf<uint8_t> d_small;   // matrix tables, policies
     DevBuf<uint8_t> d_maskws;
-    PinBuf<uint32_t> dbg;      // CRAMGPU_DEBUG=1 progress markers
-    bool debug = false;
+    DevBuf<unsigned long long> d_prof;  // CRAMGPU_PROF=1
+    bool prof_on = false;
 };
 
 namespace {
@@ -170,12 +170,29 @@ int rans_run(cramgpu_ctx* c, bool encode, const uint8_t* d_in, uint8_t* d_out, c
     a.ticket = ticket;
     a.rcp_tab = c->rcp_tab.p;
     a.tab_bytes = c->tab_bytes;
-    a.stop_phase = env_int("CRAMGPU_STOP_PHASE", 0);
-    a.dbg = c->debug ? c->dbg.p : nullptr;
-    if (c->debug) memset(c->dbg.p, 0, 64 * sizeof(uint32_t));
+    a.prof = nullptr;
+    if (encode && c->prof_on) {  // profiling aid: per-block cycle counters, printed after a synchronising copy
+        HIPCHK(c->d_prof.reserve((size_t)n * 8));
+        HIPCHK(hipMemsetAsync(c->d_prof.p, 0, (size_t)n * 8 * sizeof(unsigned long long), s));
+        a.prof = c->d_prof.p;
+    }
     if (encode) {
         a.gscratch = c->enc_gs.p;
         HIPCHK(launch_rans_encode(a, std::min(n, c->n_waves_enc), c->enc_lds, s));
+        if (a.prof) {
+            std::vector<unsigned long long> h((size_t)n * 8);
+            HIPCHK(hipMemcpyAsync(h.data(), a.prof, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            int32_t big = 0;
+            for (int32_t i = 1; i < n; i++)
+                if (blocks[i].in_len > blocks[big].in_len) big = i;
+            const unsigned long long* r = h.data() + (size_t)big * 8;
+            fprintf(stderr, "[cramgpu prof] largest block %d B: prep %llu cyc, stream %llu cyc, helper busy %llu, chain busy %llu, "
+                            "batches %llu (per step: stream %.1f, helper %.1f, chain %.1f of which record reads %.1f)\n",
+                    blocks[big].in_len, r[0], r[1], r[2], r[3], r[4], r[4] ? (double)r[1] / (16.0 * r[4]) : 0.0,
+                    r[4] ? (double)r[2] / (16.0 * r[4]) : 0.0, r[4] ? (double)r[3] / (16.0 * r[4]) : 0.0,
+                    r[4] ? (double)r[5] / (16.0 * r[4]) : 0.0);
+        }
     } else {
         a.gscratch = c->dec_gs.p;
         HIPCHK(launch_rans_decode(a, std::min(n, c->n_waves_dec), c->dec_lds, s));
@@ -225,14 +242,14 @@ cramgpu_ctx* cramgpu_open(int32_t device_index) {
     c->device = device_index;
     c->n_cu = prop.multiProcessorCount;
     const int lds_per_cu = 160 * 1024;
-    c->tab_bytes = env_int("CRAMGPU_TAB_BYTES", 24 * 1024) & ~15;
+    // LDS table region of a resident rANS workgroup: 4 encoder groups (2 waves each) per CU fill the 160 KiB
+    c->tab_bytes = env_int("CRAMGPU_TAB_BYTES", 35 * 1024) & ~15;
     if (c->tab_bytes < 20 * 1024) c->tab_bytes = 20 * 1024;  // order-0 decode needs a 16 KiB slot table
-    c->enc_lds = rans_encode_fixed_lds() + c->tab_bytes;
+    c->enc_lds = 0;  // static LDS, sized for 4 workgroups per CU (rans_enc.hip)
     c->dec_lds = rans_decode_fixed_lds() + c->tab_bytes;
-    c->enc_wpc = std::max(1, std::min(env_int("CRAMGPU_ENC_WAVES_PER_CU", 16), (int)(lds_per_cu / (c->enc_lds + 512))));
+    c->enc_wpc = std::max(1, std::min(env_int("CRAMGPU_ENC_GROUPS_PER_CU", 4), 4));
     c->dec_wpc = std::max(1, std::min(env_int("CRAMGPU_DEC_WAVES_PER_CU", 16), (int)(lds_per_cu / (c->dec_lds + 512))));
-    c->debug = env_int("CRAMGPU_DEBUG", 0) != 0;
-    if (c->debug && c->dbg.reserve(1024) != hipSuccess) c->debug = false;
+    c->prof_on = env_int("CRAMGPU_PROF", 0) != 0;
     c->n_waves_enc = c->n_cu * c->enc_wpc;
     c->n_waves_dec = c->n_cu * c->dec_wpc;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -259,7 +276,7 @@ void cramgpu_close(cramgpu_ctx* c) {
     c->h_desc.release(); c->h_perm.release(); c->d_desc.release(); c->d_perm.release();
     c->d_in.release(); c->d_out.release(); c->d_pack.release(); c->d_len.release(); c->d_pos.release();
     c->d_off.release(); c->d_err.release(); c->h_stage.release(); c->h_len.release(); c->h_off.release();
-    c->d_counts.release(); c->d_total.release(); c->h_total.release(); c->d_small.release(); c->d_maskws.release();
+    c->d_counts.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_small.release(); c->d_maskws.release(); c->d_prof.release();
     if (c->staged) (void)hipEventDestroy(c->staged);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -354,15 +371,7 @@ static int32_t host_batch(cramgpu_ctx* c, bool encode, const uint8_t* in_arena, 
                          c->d_err.p, (int32_t)std::min<int64_t>(max_cap, 0x7fffffff), s));
     HIPCHK(hipMemcpyAsync(c->h_len.p, c->d_len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(c->h_off.p, c->d_off.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    {
-        hipError_t se = hipStreamSynchronize(s);
-        if (c->debug) {
-            fprintf(stderr, "[cramgpu debug] sync=%d markers:", (int)se);
-            for (int i = 0; i < 8; i++) fprintf(stderr, " %u(0x%x)", c->dbg.p[i], c->dbg.p[i]);
-            fprintf(stderr, "\n");
-        }
-        if (se != hipSuccess) return fail(CRAMGPU_E_HIP, "hipStreamSynchronize(s)", se);
-    }
+    HIPCHK(hipStreamSynchronize(s));
     const int64_t packed = c->h_off.p[n];
     HIPCHK(c->h_stage.reserve((size_t)packed + 16));
     HIPCHK(hipMemcpyAsync(c->h_stage.p, c->d_pack.p, (size_t)packed, hipMemcpyDeviceToHost, s));
@@ -469,7 +478,8 @@ int64_t cramgpu_extract_features_dev(cramgpu_ctx* c, const cramgpu_reads* reads,
     const int32_t n = reads->n_reads;
     HIPCHK(c->d_counts.reserve((size_t)n + 1));
     if (n > 0) HIPCHK(launch_extract_features(*reads, d_ref, *feats, nullptr, c->d_counts.p, false, s));
-    HIPCHK(launch_feature_scan(n, c->d_counts.p, feats->off, c->d_total.p, s));
+    HIPCHK(c->d_scan_ws.reserve(feature_scan_ws_elems(n)));
+    HIPCHK(launch_feature_scan(n, c->d_counts.p, feats->off, c->d_total.p, c->d_scan_ws.p, s));
     HIPCHK(hipMemcpyAsync(c->h_total.p, c->d_total.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const int64_t total = c->h_total.p[0];
@@ -655,7 +665,8 @@ int64_t cramgpu_merge_quality_features_dev(cramgpu_ctx* c, int32_t n_reads, cons
     if (n_reads > 0)
         HIPCHK(launch_merge_quality(n_reads, d_read_len, d_base_off, d_scores, d_force, d_qstatus, *in, *out, c->d_counts.p,
                                     false, s));
-    HIPCHK(launch_feature_scan(n_reads, c->d_counts.p, out->off, c->d_total.p, s));
+    HIPCHK(c->d_scan_ws.reserve(feature_scan_ws_elems(n_reads)));
+    HIPCHK(launch_feature_scan(n_reads, c->d_counts.p, out->off, c->d_total.p, c->d_scan_ws.p, s));
     HIPCHK(hipMemcpyAsync(c->h_total.p, c->d_total.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const int64_t total = c->h_total.p[0];

@@ -12,19 +12,6 @@
 #define CRAMGPU_DYN_LDS(name) extern __shared__ __align__(16) uint8_t name[]
 #endif
 
-// progress marker into pinned host memory (debug builds of a run only; dbg is NULL otherwise)
-#ifdef HIP_SIM
-#define CRAMGPU_MARK(dbg, i, v) do { if (dbg) (dbg)[i] = (uint32_t)(v); } while (0)
-#else
-#define CRAMGPU_MARK(dbg, i, v)                                         \
-    do {                                                                \
-        if (dbg) {                                                      \
-            ((volatile uint32_t*)(dbg))[i] = (uint32_t)(v);             \
-            __threadfence_system();                                     \
-        }                                                               \
-    } while (0)
-#endif
-
 // Lanes of a wave execute in lock step on the GPU, so "lane A reads LDS, then (later in program order) lane B
 // overwrites it" needs nothing there; the host harness runs lanes as free threads and needs a rendezvous.
 #ifdef HIP_SIM
@@ -37,7 +24,7 @@
 #define RANS_TOTFREQ 4096
 #define RANS_BYTE_L (1u << 23)
 
-// global scratch of one resident rANS wave: order-1 tables that do not fit LDS
+// global scratch of one resident rANS workgroup: order-1 tables that do not fit LDS
 //   encode: counts u32[256][256] (256 KiB) + packed symbols uint2[256][256] (512 KiB)
 //   decode: order-1 rows u32[256][256] (256 KiB)
 #define ENC_GSCRATCH_BYTES (768u * 1024u)
@@ -52,15 +39,14 @@ struct RansArgs {
     int32_t* out_len;
     int64_t* out_pos;           // encode only
     uint32_t* ticket;           // work-queue head, zeroed before the launch
-    uint8_t* gscratch;          // n_waves x {ENC,DEC}_GSCRATCH_BYTES
+    uint8_t* gscratch;          // n_groups x {ENC,DEC}_GSCRATCH_BYTES
     const uint32_t* rcp_tab;    // [4096] Encoding#RansEncSymbolInit rcp_freq per freq
     int32_t tab_bytes;          // bytes of the LDS table region
-    int32_t stop_phase;         // CRAMGPU_STOP_PHASE debugging aid (0 = off)
-    uint32_t* dbg;              // CRAMGPU_DEBUG=1: pinned host words for progress markers, else NULL
+    unsigned long long* prof;   // CRAMGPU_PROF=1: 8 cycle counters per block (encode), else NULL
 };
 
 // launchers (defined in the .hip files)
-hipError_t launch_rans_encode(const RansArgs& a, int n_waves, size_t lds_bytes, hipStream_t s);
+hipError_t launch_rans_encode(const RansArgs& a, int n_groups, size_t lds_bytes, hipStream_t s);  // 2-wave groups
 hipError_t launch_rans_decode(const RansArgs& a, int n_waves, size_t lds_bytes, hipStream_t s);
 hipError_t launch_rcp_init(uint32_t* d_rcp_tab, hipStream_t s);
 size_t rans_encode_fixed_lds();
@@ -72,7 +58,9 @@ hipError_t launch_gather(const uint8_t* src, const int64_t* pos, const int32_t* 
 // record kernels
 hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
                                    int32_t* d_counts, bool write_pass, hipStream_t s);
-hipError_t launch_feature_scan(int32_t n_reads, const int32_t* d_counts, int64_t* d_off, int64_t* d_total, hipStream_t s);
+size_t feature_scan_ws_elems(int32_t n_reads);  // int64 elements of workspace launch_feature_scan needs
+hipError_t launch_feature_scan(int32_t n_reads, const int32_t* d_counts, int64_t* d_off, int64_t* d_total, int64_t* d_ws,
+                               hipStream_t s);
 hipError_t launch_assign_codes(int32_t n_reads, const int32_t* read_cont, const int64_t* off, const uint8_t* op,
                                int32_t* a, const uint8_t* d_codes, hipStream_t s);
 hipError_t launch_restore_bases(int32_t n_reads, const int32_t* read_len, const int32_t* aln_start, const uint8_t* rflags,

@@ -8,26 +8,36 @@
 //
 // Execution model.  A CRAM block is one rANS stream whose four interleaved states form four strictly serial
 // dependency chains; byte identity forbids re-blocking, so the only parallelism inside a block is (a) the four
-// states and (b) everything that does not depend on the states.  The kernel is a resident grid of single-wave
-// workgroups that pull blocks (longest first) from a ticket counter.  For its block a wave
-//   1. histograms the input with all 64 lanes (LDS counters, lane-replicated for small alphabets),
-//   2. normalises, serialises the frequency table and builds packed encoder symbols, one table row per lane,
-//   3. encodes in batches of 16 steps: all 64 lanes fetch symbol/context bytes and expand the 64 encoder symbols
-//      of the batch into an LDS staging area; lanes 0-3 run the four state chains reading that area at fixed
-//      offsets and log the pre-renormalisation states; then all 64 lanes turn the logged states into output
-//      bytes, placed with a ballot/popcount prefix in the reference's emission order (state 3,2,1,0 per step).
-//      Bytes are written from the end of the block's slot downwards, which realises Utils#reverse for free.
+// states and (b) everything that does not depend on the states.  One wave issues one vector instruction per ~4.4
+// cycles whether or not the instructions depend on each other (scripts/ubench/lat_bench.hip), so the time of a block
+// is (instructions the chain's wave issues per step) x 4.4 cycles x steps: everything that is not the chain is
+// moved OFF the chain's wave.  The kernel is a resident grid of two-wave workgroups pulling blocks (longest first)
+// from a ticket counter:
+//   wave 1 ("helper")  1. histograms the input (LDS counters, lane-replicated for small alphabets),
+//                      2. normalises, serialises the frequency table, builds packed encoder symbols (a row per lane),
+//                      3. per batch of 16 coding steps: fetches the 64 symbol/context bytes, looks the symbols up and
+//                         expands them into a 16-byte record per (step, state) in an LDS staging buffer; turns the
+//                         states the chain logged for the previous batch into output bytes, placed with a
+//                         ballot/popcount prefix in the reference's emission order (state 3,2,1,0 per step) and
+//                         written from the end of the slot downwards, which realises Utils#reverse for free.
+//   wave 0 ("chain")   per step and state (lanes 0-3): one 16-byte LDS read, compare, conditional shift, mul_hi, shift,
+//                      24-bit multiply, add — Encoding#RansEncPutSymbol with everything state-independent removed —
+//                      and logs the pre-renormalisation states of a batch with four 16-byte LDS writes.
+// The two waves meet at one workgroup barrier per batch; staging and log are double buffered.
 // Order-1 tables live in LDS over the compacted alphabet (present symbols + 0) when n*(n|1)*12 B fits the table
-// region, else in a per-wave global scratch over the full 256x256 alphabet.
+// region, else in a per-workgroup global scratch over the full 256x256 alphabet.
 #include <climits>
 
 #include "internal.h"
 
 namespace {
 
-constexpr int kSteps = 16;  // steps per batch: 16 steps x 4 states = 64 lanes
+constexpr int kSteps = 16;  // steps per batch: 16 steps x 4 states = 64 lanes of the helper wave
 
-struct EncFixedLds {
+constexpr int kRingBytes = 4096;  // input ring of the helper wave: 4 x 1 KiB (order 1) or 1 x 4 KiB (order 0)
+
+// LDS of one workgroup, statically sized so that 4 workgroups fill the 160 KiB of a CU.
+struct alignas(16) EncFixed {
     union {
         struct {                    // phase 2 (tables)
             uint32_t rowT[256];     // order-1 row totals (0 = context absent)
@@ -35,16 +45,54 @@ struct EncFixedLds {
             uint32_t rowhdr[256];   // context-level header of each row: count | byte0 << 8 | byte1 << 16
         } p2;
         struct {                    // phase 3 (coding loop)
-            uint4 stageA[2][64];    // x_max, x_max<<8 (saturated), rcp_freq, bias     (double buffered)
-            uint2 stageB[2][64];    // cmpl_freq, rcp_shift-32
-            uint32_t xs[kSteps][64];  // state of every lane before each step of the current batch
+            uint4 stage[2][64];     // [buffer][step*4 + state]: x_max, rcp_freq, bias, cmpl_freq | shift<<24 | small<<31
+            uint4 xs[2][4][4];      // [buffer][state][step/4]: state before each step of the batch
+            uint8_t ring[kRingBytes];  // input bytes (dense symbol indices when the order-1 tables are in LDS)
+            uint32_t fin[4];        // states after the last batch the chain ran
+            unsigned long long cbusy, cbusy2;  // profiling runs only: cycles the chain wave spent outside barriers
         } p3;
     };
     uint8_t dmap[256];    // byte value -> dense index
     uint8_t syml[256];    // dense index -> byte value
+    // block hand-over between the waves (written by the helper wave, read by both after a barrier)
+    int32_t mode, stride, ent_off, tab_len, status;
+    uint32_t ticket;
+    uint32_t pad[2];
 };
+constexpr int kTabBytes = ((160 * 1024 / 4 - (int)sizeof(EncFixed)) & ~255) - 256;  // table region (counts, symbols, replicas)
+struct alignas(16) EncLds : EncFixed {
+    alignas(16) uint8_t tab[kTabBytes];
+};
+typedef EncLds EncFixedLds;  // phases 1 and 2 only touch the fixed part
+#ifdef HIP_SIM
+static EncLds lds;
+#else
+__shared__ EncLds lds;
+#endif
 
-__device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
+// A value that is the same in every lane of the wave, moved to a scalar register so that branches on it are scalar
+// branches: a wave then never walks a path of the other wave's role with an empty EXEC mask (where a barrier would
+// still count).
+#ifdef HIP_SIM
+#define UNIFORM(x) (x)
+#else
+#define UNIFORM(x) __builtin_amdgcn_readfirstlane((int)(x))
+#endif
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return UNIFORM(threadIdx.x >> 6); }
+
+// Synchronisation among the lanes of ONE wave (phases 1 and 2 run in the helper wave alone while the chain wave
+// waits at the workgroup barrier): LDS operations of a wave execute in order, so only the compiler has to be held.
+__device__ __forceinline__ void wave_sync() {
+#ifdef HIP_SIM
+    __builtin_amdgcn_wave_barrier();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+#define WSYNC() wave_sync()
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -92,15 +140,17 @@ __device__ __forceinline__ uint2 pack_symbol(int32_t freq, uint32_t start, const
     return make_uint2(rcp, f | ((bias & 8191u) << 12) | (sh << 25));
 }
 
-// expand a packed symbol into the staged form the state lanes consume
-__device__ __forceinline__ void expand_symbol(uint2 e, uint4& A, uint2& B) {
-    uint32_t f = e.y & 4095u;
-    A.x = f << 19;                              // x_max = ((L >> 12) << 8) * freq
-    A.y = f < 16 ? (f << 27) : 0xFFFFFFFFu;     // second renormalisation byte iff x >= x_max << 8 (x < 2^31)
-    A.z = e.x;
-    A.w = (e.y >> 12) & 8191u;
-    B.x = 4096u - f;
-    B.y = e.y >> 25;
+// expand a packed symbol into the 16-byte record the chain wave consumes
+__device__ __forceinline__ uint4 expand_symbol(uint2 e) {
+    const uint32_t f = e.y & 4095u;
+    uint4 A;
+    A.x = f << 19;                 // x_max = ((L >> 12) << 8) * freq
+    A.y = e.x;                     // rcp_freq
+    A.z = (e.y >> 12) & 8191u;     // bias
+    // cmpl_freq in the low 24 bits (all a 24-bit multiply reads), rcp_shift-32 in bits 24..28 (all a shift reads of
+    // its count), bit 31: freq < 16, i.e. x_max < L and the first renormalisation byte is certain
+    A.w = (4096u - f) | ((e.y >> 25) << 24) | (f < 16u ? 0x80000000u : 0u);
+    return A;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -110,7 +160,7 @@ __device__ __forceinline__ void expand_symbol(uint2 e, uint4& A, uint2& B) {
 __device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* rep, int R) {
     const int l = lane_id();
     for (int i = l; i < R * 256; i += 64) rep[i] = 0;
-    __syncthreads();
+    WSYNC();
     uint32_t* my = rep + (l & (R - 1)) * 256;
     const int32_t n16 = n & ~15;
     for (int32_t i = l * 16; i < n16; i += 64 * 16) {
@@ -125,13 +175,13 @@ __device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* 
         }
     }
     if (n16 + l < n) atomicAdd(&my[src[n16 + l]], 1u);
-    __syncthreads();
+    WSYNC();
     for (int j = l; j < 256; j += 64) {
         uint32_t s = 0;
         for (int r = 0; r < R; r++) s += rep[r * 256 + j];
         cnt[j] = s;
     }
-    __syncthreads();
+    WSYNC();
 }
 
 // order-1 pair counts: cnt[row(prev)*stride + col(cur)] with prev = 0 before the first byte
@@ -146,7 +196,7 @@ __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n,
         for (int i = l; i < R * rstride; i += 64) rep[i] = 0;
         my = rep + (l & (R - 1)) * rstride;
     }
-    __syncthreads();
+    WSYNC();
     const int32_t n16 = n & ~15;
     for (int32_t i = l * 16; i < n16; i += 64 * 16) {
         uint4 v = *reinterpret_cast<const uint4*>(src + i);
@@ -177,14 +227,14 @@ __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n,
             atomicAdd(&my[(uint32_t)dmap[c]], 1u);
         }
     }
-    __syncthreads();
+    WSYNC();
     if (R > 1) {
         for (int j = l; j < cells; j += 64) {
             uint32_t s = 0;
             for (int r = 0; r < R; r++) s += rep[r * rstride + j];
             cnt[j] += s;
         }
-        __syncthreads();
+        WSYNC();
     }
 }
 
@@ -230,7 +280,7 @@ __device__ int row_body(const uint32_t* c, int n, const uint8_t* syml, uint8_t* 
 // order-1: normalise rows (L175-193), serialise (writeFrequencies_o1 L269-328), build symbols (buildSyms_o1 L248-265).
 // Returns the table length; table bytes go to tabdst.
 __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent, int nrows, int n, int stride, EncFixedLds* L, uint8_t* tabdst,
-                             const uint32_t* rcp_tab, int32_t tab_cap, uint32_t* dbg = nullptr, int stop = 0) {
+                             const uint32_t* rcp_tab, int32_t tab_cap) {
     const int l = lane_id();
     const int rpl = (nrows + 63) >> 6;  // rows per lane, contiguous so a lane scan gives row order
     // normalise
@@ -260,9 +310,7 @@ __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent
         t2++;
         c[M] = (uint32_t)((int32_t)c[M] + (RANS_TOTFREQ - t2));
     }
-    __syncthreads();
-    if (stop == 3) return -53;
-    if (lane_id() == 0) CRAMGPU_MARK(dbg, 1, 50);
+    WSYNC();
     // serialised length of each present row: context header (index byte, run byte) + body.  The header is kept in
     // LDS (count | byte0 << 8 | byte1 << 16, in the high half of rowoff) so that the write pass only replays it.
     uint32_t mylen = 0;
@@ -293,12 +341,7 @@ __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent
     }
     uint32_t total;
     uint32_t base = wave_excl_scan(mylen, total);
-    __syncthreads();
-    if (lane_id() == 0) {
-        CRAMGPU_MARK(dbg, 1, 51);
-        CRAMGPU_MARK(dbg, 2, total);
-    }
-    if (stop == 4) return -54;
+    WSYNC();
     // RANS#allocateIfNeeded L79-85 budgets 257*257*3 bytes for the table; nothing larger can be a valid table, and
     // every row is written strictly inside [0, total): a stray length can therefore never leave the block's slot
     if (total > 257u * 257u * 3u || (int64_t)total + 1 > (int64_t)tab_cap) return CRAMGPU_E_INSUFFICIENT;
@@ -317,9 +360,7 @@ __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent
         base += len;
     }
     if (l == 0) tabdst[total] = 0;
-    if (l == 0) CRAMGPU_MARK(dbg, 1, 52);
-    __syncthreads();
-    if (stop == 5) return -55;
+    WSYNC();
     // encoder symbols
 #pragma unroll 1
     for (int k = 0; k < rpl; k++) {
@@ -336,8 +377,7 @@ __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent
             C += (uint32_t)f;
         }
     }
-    __syncthreads();
-    if (stop == 6) return -56;
+    WSYNC();
     return (int32_t)total + 1;
 }
 
@@ -388,209 +428,373 @@ __device__ int32_t tables_o0(uint32_t* cnt, uint2* ent, int32_t n_in, EncFixedLd
         if (c4[k] != 0) ent[j] = pack_symbol((int32_t)c4[k], pre, rcp_tab);
         pre += c4[k];
     }
-    __syncthreads();
+    WSYNC();
     int32_t len = 0;
     if (l == 0) {
         len = row_body<false>(cnt, 256, L->syml, nullptr);
         if (len <= tab_cap) row_body<true>(cnt, 256, L->syml, tabdst);
     }
     len = __shfl(len, 0);
-    __syncthreads();
+    WSYNC();
     return len;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// phase 3: the coding loop
+// phase 3: the coding loop (both waves)
 // ---------------------------------------------------------------------------------------------------------
 enum { MODE_O0 = 0, MODE_O1_LDS = 1, MODE_O1_GLOBAL = 2 };
 
-// The bytes one lane prepares for a batch: lane (t, j) owns step ub + t of state j.
-struct Fetch {
-    uint32_t sym, ctx;
-    bool act;
-};
-
-template <int MODE>
-__device__ __forceinline__ Fetch fetch_batch(const uint8_t* src, int32_t n, int32_t q, int32_t rem, int32_t U, int32_t ub,
-                                             int t, int j) {
-    Fetch f{0u, 0u, false};
-    const int32_t u = ub + t;
-    bool act = u < U;
-    int32_t pos = 0;
-    if (MODE == MODE_O0) {
-        pos = (n & ~3) - 4 * u + j;
-        act = act && pos < n;  // u == 0: only states j < (n&3)
-    } else {
-        int32_t k;
-        if (j == 3) {
-            k = U - 1 - u;
-            pos = 3 * q + k;
-        } else {
-            k = q - 1 - (u - rem);
-            pos = j * q + k;
-            act = act && u >= rem;
-        }
-        if (act && k > 0) f.ctx = src[pos - 1];  // k == 0: the quarter's first symbol is coded in context 0
-    }
-    if (act) f.sym = src[pos];
-    f.act = act;
-    return f;
-}
-
-template <int MODE>
-__device__ __forceinline__ void stage_batch(const Fetch& f, const uint2* ent, int stride, EncFixedLds* L, int buf, int slot,
-                                            uint4& A) {
-    A = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);  // identity step for inactive (step, state) pairs
-    uint2 B = make_uint2(0u, 0u);
-    if (f.act) {
-        uint2 e;
-        if (MODE == MODE_O0)
-            e = ent[f.sym];
-        else if (MODE == MODE_O1_LDS)
-            e = ent[(uint32_t)L->dmap[f.ctx] * (uint32_t)stride + L->dmap[f.sym]];
-        else
-            e = ent[f.ctx * 256u + f.sym];
-        expand_symbol(e, A, B);
-    }
-    L->p3.stageA[buf][slot] = A;
-    L->p3.stageB[buf][slot] = B;
-}
-
-// Returns payload length (including the 16 state bytes) or a negative code.  Payload is written downwards from pend.
-// Software pipeline over batches of 16 steps, all in one loop body so that the scheduler can fill the latency gaps of
-// the serial chain: iteration i  (a) stages batch i+1 (symbol lookup + expansion, from bytes fetched one iteration
-// earlier) and fetches the bytes of batch i+2,  (b) runs the 16 chain steps of batch i,  (c) turns the logged states
-// of batch i-1 into output bytes.  The chain is executed by ALL lanes (lane l replicates state l&3): that costs
-// nothing on a SIMD and keeps EXEC constant, which is what lets (a) and (c) interleave with (b).
-template <int MODE>
-__device__ int32_t encode_stream(const uint8_t* src, int32_t n, const uint2* ent, int stride, EncFixedLds* L,
-                                 uint8_t* pend, int32_t room, uint32_t* dbg = nullptr) {
-    (void)dbg;
-    const int l = lane_id();
-    const int t = l >> 2, j = 3 - (l & 3), sl = l & 3;
-    const int slot = t * 4 + j;
-    const int32_t q = n >> 2;
-    int32_t U, rem = 0;
-    if (MODE == MODE_O0) {
-        U = q + 1;  // step 0 is the n&3 tail (E04 L17-33), then q full steps
-    } else {
-        rem = n - 4 * q;  // state 3 codes the remainder alone first (E14 L27-31)
-        U = q + rem;
-    }
-    const int32_t nbatch = (U + kSteps - 1) / kSteps;
-    uint32_t x = RANS_BYTE_L;
-    int32_t run = 0;
-    const int32_t limit = room - 16;
-    uint4 A, prevA = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-    Fetch f = fetch_batch<MODE>(src, n, q, rem, U, 0, t, j);
-    stage_batch<MODE>(f, ent, stride, L, 0, slot, A);
-    f = fetch_batch<MODE>(src, n, q, rem, U, kSteps, t, j);
+// Barrier between the two waves of the workgroup.  Only LDS traffic is exchanged across it, so it waits for the LDS
+// counter alone: __syncthreads() would also drain the helper wave's global loads and stores (a full memory round
+// trip per batch).
+__device__ __forceinline__ void pair_barrier() {
+#ifdef HIP_SIM
     __syncthreads();
-    for (int32_t i = 0; i < nbatch; i++) {
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// Input positions.  Step u of state j codes the byte at pos(u, j); positions fall by one per step inside a state's
+// stream (order 1: four quarters; order 0: one interleaved stream, four bytes per step).
+//   order 0 (E04 L12-57):  pos = (n & ~3) - 4u + j, step 0 is the n&3 tail (only states j < (n&3))
+//   order 1 (E14 L13-86):  pos = top_j - u with top_3 = 3q + U - 1 and top_j = jq + q - 1 + rem for j < 3; states
+//                          0-2 are idle during the first rem steps (state 3 codes the remainder alone, L27-31); the
+//                          first byte of a quarter is coded in context 0.
+struct Geo {
+    int32_t n, q, rem, U;
+};
+template <int MODE>
+__device__ __forceinline__ int32_t pos_of(const Geo& g, int32_t u, int j) {
+    if (MODE == MODE_O0) return (g.n & ~3) - 4 * u + j;
+    return (j == 3 ? 3 * g.q + g.U - 1 : j * g.q + g.q - 1 + g.rem) - u;
+}
+template <int MODE>
+__device__ __forceinline__ bool active_of(const Geo& g, int32_t u, int j, int32_t pos) {
+    if (u >= g.U) return false;
+    if (MODE == MODE_O0) return pos < g.n;
+    return j == 3 || u >= g.rem;
+}
+// ring address of input position pos of state j: the ring holds dense symbol indices (order 1, LDS tables) or bytes
+template <int MODE>
+__device__ __forceinline__ int ring_addr(int32_t pos, int j) {
+    if (MODE == MODE_O0) return pos & (kRingBytes - 1);
+    return j * (kRingBytes / 4) + (pos & (kRingBytes / 4 - 1));
+}
+
+constexpr int kChunkSteps = 256;  // steps per input chunk = 16 batches
+
+// One input chunk = the positions steps [256c, 256c + 256) touch, as 16-byte units: order 0 one run of <= 65 units,
+// order 1 four runs (one per quarter) of <= 18 units.  A lane owns up to two units.
+struct ChunkRegs {
+    uint4 v[2];
+    int32_t pos[2];  // first position of the unit, -1 = none
+    int ring[2];
+};
+template <int MODE>
+__device__ __forceinline__ void chunk_load(const uint8_t* src, const Geo& g, int32_t c, int l, ChunkRegs& R) {
+    const int32_t u0 = c * kChunkSteps, u1 = u0 + kChunkSteps - 1;
+    int j;
+    int32_t hi, lo;
+    int first;
+    if (MODE == MODE_O0) {
+        j = 0;
+        hi = pos_of<MODE>(g, u0, 3);
+        lo = pos_of<MODE>(g, u1, 0);
+        first = l;
+    } else {
+        j = l >> 4;
+        hi = pos_of<MODE>(g, u0, j);
+        lo = pos_of<MODE>(g, u1, j) - 1;  // context byte of the last step
+        first = l & 15;
+    }
+    if (lo < 0) lo = 0;
+    if (hi > g.n - 1) hi = g.n - 1;
+    const int32_t alo = lo & ~15;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int32_t p = alo + 16 * (first + (MODE == MODE_O0 ? 64 : 16) * k);
+        R.pos[k] = -1;
+        R.v[k] = make_uint4(0, 0, 0, 0);
+        if (hi >= 0 && p <= hi) {  // the arena is padded to 16 bytes, a unit may be read whole
+            R.pos[k] = p;
+            R.ring[k] = ring_addr<MODE>(p, j);
+            R.v[k] = *reinterpret_cast<const uint4*>(src + p);
+        }
+    }
+}
+__device__ __forceinline__ uint32_t dense4(uint32_t w, const uint8_t* dmap) {
+    return (uint32_t)dmap[w & 255u] | ((uint32_t)dmap[(w >> 8) & 255u] << 8) | ((uint32_t)dmap[(w >> 16) & 255u] << 16) |
+           ((uint32_t)dmap[w >> 24] << 24);
+}
+template <int MODE>
+__device__ __forceinline__ void chunk_store(const ChunkRegs& R, uint8_t* ring, const uint8_t* dmap) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (R.pos[k] >= 0) {
+            uint4 v = R.v[k];
+            if (MODE == MODE_O1_LDS) v = make_uint4(dense4(v.x, dmap), dense4(v.y, dmap), dense4(v.z, dmap), dense4(v.w, dmap));
+            *reinterpret_cast<uint4*>(ring + R.ring[k]) = v;
+        }
+    }
+}
+
+// Helper lane l owns step (l >> 2) and state 3 - (l & 3) of a batch, so that lane order is the reference's emission
+// order.  lookup: ring -> packed symbol (valid = the pair is active).
+template <int MODE>
+__device__ __forceinline__ uint2 lookup_entry(const Geo& g, int32_t u, int j, const uint8_t* ring, const uint2* ent, int stride,
+                                              bool& act) {
+    const int32_t pos = pos_of<MODE>(g, u, j);
+    act = active_of<MODE>(g, u, j, pos);
+    uint2 e = make_uint2(0u, 0u);
+    if (act) {
+        const uint32_t sym = ring[ring_addr<MODE>(pos, j)];
+        if (MODE == MODE_O0) {
+            e = ent[sym];
+        } else {
+            const bool first = pos == j * g.q;  // first byte of the quarter: context 0
+            const uint32_t ctx = first ? 0u : ring[ring_addr<MODE>(pos - 1, j)];
+            e = ent[ctx * (uint32_t)stride + sym];
+        }
+    }
+    return e;
+}
+
+// Encoding#RansEncPutSymbol L46-71 for 16 steps of one state (chain wave, lanes 0-3 = states 0-3); the state before
+// every step is logged to xs[step] for the helper wave.
+// GENERAL: the batch holds symbols with freq < 16, whose first renormalisation byte is certain (x >= L > x_max).
+template <bool GENERAL>
+__device__ __forceinline__ uint32_t chain_steps(uint32_t x, const uint4 (&P)[kSteps], uint32_t* xs) {
+#pragma unroll
+    for (int tt = 0; tt < kSteps; tt++) {
+        xs[tt] = x;
+        if (GENERAL) x = (int32_t)P[tt].w < 0 ? x >> 8 : x;
+        const uint32_t xr = x >= P[tt].x ? x >> 8 : x;
+        const uint32_t qq = __umulhi(xr, P[tt].y) >> ((P[tt].w >> 24) & 31u);  // qq < 2^19, cmpl_freq < 2^12
+        x = xr + P[tt].z + __umul24(qq, P[tt].w);
+    }
+    return x;
+}
+
+#ifndef HIP_SIM
+// The same steps (freq >= 16 only) scheduled by hand: 8 issue slots per step.  A lone wave issues one instruction per
+// ~4.4 cycles and v_cndmask needs two other instructions between it and the v_cmp that wrote VCC; the shift and the
+// log write fill those slots (the compiler pads them with s_nop).  The shift count is byte 3 of the record's last word
+// (SDWA), the 24-bit multiply ignores that byte.
+#define RANS_STEP(K)                                                                                          \
+    "v_cmp_lt_u32 vcc, %[x], %[a" #K "]\n\t"                                                                  \
+    "v_lshrrev_b32 %[t], 8, %[x]\n\t"                                                                         \
+    "ds_write_b32 %[adr], %[x] offset:%c[o" #K "]\n\t"                                                        \
+    "v_cndmask_b32 %[x], %[t], %[x], vcc\n\t"                                                                 \
+    "v_mul_hi_u32 %[m], %[x], %[b" #K "]\n\t"                                                                 \
+    "v_lshrrev_b32_sdwa %[m], %[d" #K "], %[m] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t" \
+    "v_mul_u32_u24 %[m], %[m], %[d" #K "]\n\t"                                                                \
+    "v_add3_u32 %[x], %[x], %[c" #K "], %[m]\n\t"
+__device__ __forceinline__ uint32_t chain_steps_fast(uint32_t x, const uint4 (&P)[kSteps], uint32_t xs_lds) {
+#pragma unroll
+    for (int g = 0; g < kSteps; g += 4) {
+        uint32_t t, m;
+        asm volatile(RANS_STEP(0) RANS_STEP(1) RANS_STEP(2) RANS_STEP(3)
+                     : [x] "+v"(x), [t] "=&v"(t), [m] "=&v"(m)
+                     : [adr] "v"(xs_lds), [o0] "n"(0), [o1] "n"(4), [o2] "n"(8), [o3] "n"(12),
+                       [a0] "v"(P[g].x), [b0] "v"(P[g].y), [c0] "v"(P[g].z), [d0] "v"(P[g].w),
+                       [a1] "v"(P[g + 1].x), [b1] "v"(P[g + 1].y), [c1] "v"(P[g + 1].z), [d1] "v"(P[g + 1].w),
+                       [a2] "v"(P[g + 2].x), [b2] "v"(P[g + 2].y), [c2] "v"(P[g + 2].z), [d2] "v"(P[g + 2].w),
+                       [a3] "v"(P[g + 3].x), [b3] "v"(P[g + 3].y), [c3] "v"(P[g + 3].z), [d3] "v"(P[g + 3].w)
+                     : "vcc", "memory");
+        xs_lds += 16;
+    }
+    return x;
+}
+#endif
+
+// Collective over both waves.  Returns (in the helper wave) the payload length including the 16 state bytes, or a
+// negative code.  The payload is written downwards from pend.
+// Iteration i: the chain wave runs batch i from stage[i&1] and logs into xs[i&1]; the helper wave turns the log of batch
+// i-1 into bytes, expands the symbols of batch i+1 into stage[(i+1)&1] and looks up the symbols of batch i+2; one
+// barrier.  Input reaches the helper through an LDS ring that is refilled with 16-byte loads a whole chunk (16
+// batches) before it is needed, so that no iteration waits for global memory.
+template <int MODE>
+__device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* ent, int stride_, uint8_t* pend, int32_t room_,
+                                 unsigned long long* prof) {
+    EncLds* L = &lds;
+    const int32_t n = UNIFORM(n_), stride = UNIFORM(stride_), room = UNIFORM(room_);  // arrive in vector registers
+    const int l = lane_id();
+    const bool helper = wave_id() == 1;
+    const int t = l >> 2, j = 3 - (l & 3);
+    const int slot = t * 4 + j;
+    Geo g;
+    g.n = n;
+    g.q = n >> 2;
+    g.rem = MODE == MODE_O0 ? 0 : n - 4 * g.q;
+    g.U = MODE == MODE_O0 ? g.q + 1 : g.q + g.rem;
+    const int32_t nbatch = (g.U + kSteps - 1) / kSteps;
+    const int32_t limit = room - 16;
+    const uint4 ident = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);  // identity step for inactive (step, state) pairs
+    uint32_t x = RANS_BYTE_L;  // chain wave
+    uint4 A0 = ident, A1 = ident;  // helper wave: records of batch i and batch i-1
+    uint2 e2 = make_uint2(0u, 0u);
+    bool act2 = false;             // looked-up symbol of batch i+2 (then i+1)
+    ChunkRegs CR;
+    int32_t run = 0;
+    bool failed = false;
+    if (helper) {
+        chunk_load<MODE>(src, g, 0, l, CR);
+        chunk_store<MODE>(CR, L->p3.ring, L->dmap);
+        chunk_load<MODE>(src, g, 1, l, CR);
+        WSYNC();
+        bool act0;
+        const uint2 e0 = lookup_entry<MODE>(g, t, j, L->p3.ring, ent, stride, act0);
+        A0 = act0 ? expand_symbol(e0) : ident;
+        const unsigned long long sm = __ballot((int32_t)A0.w < 0);
+        uint4 W = A0;
+        if (t == 0 && sm != 0) W.w |= 0x40000000u;  // bit 30 of the step-0 records: the batch needs the general chain
+        L->p3.stage[0][slot] = W;
+        e2 = lookup_entry<MODE>(g, kSteps + t, j, L->p3.ring, ent, stride, act2);
+    }
+    pair_barrier();
+#ifndef HIP_SIM
+    if (!helper) __builtin_amdgcn_s_setprio(3);  // the chain wave is the critical path of the block
+#endif
+    unsigned long long busy = 0, busy2 = 0;
+    for (int32_t i = 0; i <= nbatch; i++) {
         const int buf = i & 1;
-        // (c) states logged by the previous batch (read before this batch overwrites the log)
-        const uint32_t xv = L->p3.xs[t][3 - (l & 3)];
-        CRAMGPU_LOCKSTEP();
-        // (a) stage batch i+1, fetch batch i+2
-        uint4 An;
-        stage_batch<MODE>(f, ent, stride, L, buf ^ 1, slot, An);
-        f = fetch_batch<MODE>(src, n, q, rem, U, (i + 2) * kSteps, t, j);
-        // (b) Encoding#RansEncPutSymbol L46-71, 16 steps
-        // all 16 staged symbols go to registers first so that no LDS latency sits between two chain steps
-        uint4 sa[kSteps];
-        uint2 sb[kSteps];
+        const long long tb = prof ? clock64() : 0;
+        if (!helper) {
+            if (i < nbatch && l < 4) {
+                uint4 P[kSteps];
 #pragma unroll
-        for (int tt = 0; tt < kSteps; tt++) {
-            sa[tt] = L->p3.stageA[buf][tt * 4 + sl];
-            sb[tt] = L->p3.stageB[buf][tt * 4 + sl];
+                for (int tt = 0; tt < kSteps; tt++) P[tt] = L->p3.stage[buf][tt * 4 + l];
+                uint32_t* xs = reinterpret_cast<uint32_t*>(&L->p3.xs[buf][l][0]);
+                const bool general = (UNIFORM(P[0].w) & 0x40000000u) != 0;
+                if (prof) busy2 += (unsigned long long)(clock64() - tb);
+                if (general) {
+                    x = chain_steps<true>(x, P, xs);
+                } else {
+#ifdef HIP_SIM
+                    x = chain_steps<false>(x, P, xs);
+#else
+                    x = chain_steps_fast(x, P, (uint32_t)(uintptr_t)xs);  // low half of a generic LDS address = LDS offset
+#endif
+                }
+                L->p3.fin[l] = x;
+            }
+        } else {
+            if (i >= 1) {
+                // bytes of batch i-1 in the reference's emission order (state 3,2,1,0 per step = lane order)
+                const uint32_t xv = reinterpret_cast<const uint32_t*>(&L->p3.xs[buf ^ 1][0][0])[j * kSteps + t];
+                const bool small = (int32_t)A1.w < 0;
+                const uint32_t x1 = small ? xv >> 8 : xv;
+                const int nb = (small ? 1 : 0) + (x1 >= A1.x ? 1 : 0);
+                const unsigned long long m1 = __ballot(nb >= 1), m2 = __ballot(nb == 2);
+                const int32_t tot = __popcll(m1) + __popcll(m2);
+                if (run + tot > limit) failed = true;
+                if (!failed) {
+                    const int32_t idx = run + (int32_t)(mbcnt(m1) + mbcnt(m2));
+                    if (nb >= 1) pend[-1 - idx] = (uint8_t)xv;
+                    if (nb == 2) pend[-2 - idx] = (uint8_t)(xv >> 8);
+                    run += tot;
+                }
+            }
+            // batch i+1: expand the symbol looked up one iteration ago
+            const uint4 An = act2 ? expand_symbol(e2) : ident;
+            const unsigned long long sm = __ballot((int32_t)An.w < 0);
+            uint4 W = An;
+            if (t == 0 && sm != 0) W.w |= 0x40000000u;
+            L->p3.stage[buf ^ 1][slot] = W;
+            A1 = A0;
+            A0 = An;
+            // input ring: chunk c is needed from iteration 16c - 2 on; it is written at 16c - 8 from the registers that
+            // were loaded at 16c - 24, and the next chunk's loads are issued
+            if ((i & 15) == 8) {
+                chunk_store<MODE>(CR, L->p3.ring, L->dmap);
+                chunk_load<MODE>(src, g, (i + 8) / 16 + 1, l, CR);
+                WSYNC();
+            }
+            // batch i+2: symbol lookup
+            e2 = lookup_entry<MODE>(g, (i + 2) * kSteps + t, j, L->p3.ring, ent, stride, act2);
         }
-#pragma unroll
-        for (int tt = 0; tt < kSteps; tt++) {
-            L->p3.xs[tt][l] = x;
-            const bool r1 = x >= sa[tt].x, r2 = x >= sa[tt].y;  // two independent compares, then two selects
-            const uint32_t sh = r2 ? 16u : (r1 ? 8u : 0u);
-            const uint32_t xr = x >> sh;
-            const uint32_t qq = __umulhi(xr, sa[tt].z) >> sb[tt].y;  // qq < 2^19, cmpl_freq < 2^12: 24-bit multiply is exact
-            x = __umul24(qq, sb[tt].x) + (xr + sa[tt].w);
-        }
-        // (c) bytes of batch i-1 in the reference's emission order (state 3,2,1,0 per step = lane order)
-        if (i > 0) {
-            const int nb = (xv >= prevA.x ? 1 : 0) + (xv >= prevA.y ? 1 : 0);
-            const unsigned long long m1 = __ballot(nb >= 1), m2 = __ballot(nb == 2);
-            const int32_t tot = __popcll(m1) + __popcll(m2);
-            if (run + tot > limit) return CRAMGPU_E_INSUFFICIENT;
-            const int32_t idx = run + (int32_t)(mbcnt(m1) + mbcnt(m2));
-            if (nb >= 1) pend[-1 - idx] = (uint8_t)xv;
-            if (nb == 2) pend[-2 - idx] = (uint8_t)(xv >> 8);
-            run += tot;
-        }
-        prevA = A;
-        A = An;
-        __syncthreads();
+        if (prof) busy += (unsigned long long)(clock64() - tb);
+        pair_barrier();
     }
-    if (nbatch > 0) {
-        const uint32_t xv = L->p3.xs[t][3 - (l & 3)];
-        const int nb = (xv >= prevA.x ? 1 : 0) + (xv >= prevA.y ? 1 : 0);
-        const unsigned long long m1 = __ballot(nb >= 1), m2 = __ballot(nb == 2);
-        const int32_t tot = __popcll(m1) + __popcll(m2);
-        if (run + tot > limit) return CRAMGPU_E_INSUFFICIENT;
-        const int32_t idx = run + (int32_t)(mbcnt(m1) + mbcnt(m2));
-        if (nb >= 1) pend[-1 - idx] = (uint8_t)xv;
-        if (nb == 2) pend[-2 - idx] = (uint8_t)(xv >> 8);
-        run += tot;
+#ifndef HIP_SIM
+    if (!helper) __builtin_amdgcn_s_setprio(0);
+#endif
+    if (prof) {
+        if (!helper && l == 0) {
+            L->p3.cbusy = busy;
+            L->p3.cbusy2 = busy2;
+        }
+        pair_barrier();
+        if (helper && l == 0) {
+            prof[2] = busy;
+            prof[3] = L->p3.cbusy;
+            prof[5] = L->p3.cbusy2;
+            prof[4] = (unsigned long long)nbatch;
+        }
     }
+    if (!helper) return 0;
+    if (failed) return CRAMGPU_E_INSUFFICIENT;
     // E04 L49-53 / E14 L78-82: big-endian rans3..rans0, then Utils#reverse => stream starts LE rans0..rans3
     if (l < 4) {
+        const uint32_t xf = L->p3.fin[l];
         uint8_t* p = pend - run - 16 + 4 * l;
-        p[0] = (uint8_t)x;
-        p[1] = (uint8_t)(x >> 8);
-        p[2] = (uint8_t)(x >> 16);
-        p[3] = (uint8_t)(x >> 24);
+        p[0] = (uint8_t)xf;
+        p[1] = (uint8_t)(xf >> 8);
+        p[2] = (uint8_t)(xf >> 16);
+        p[3] = (uint8_t)(xf >> 24);
     }
     return run + 16;
 }
 
-// One block's coding work is split into three non-inlined functions (order 0, order 1 with LDS tables, order 1 with
-// global tables) so that each gets its own register allocation: inlined into one body the kernel needed ~50 SGPR
-// spills, and the wide-alphabet path misbehaved on hardware in exactly that build.
+// Each mode's coding loop is a non-inlined function so that it gets its own register allocation.
 struct Blk {
     const uint8_t* src;
     uint8_t* slot;
     uint8_t* gs;
     const uint32_t* rcp_tab;
-    uint32_t* dbg;
-    int32_t n, cap, tab_bytes, stop;
+    unsigned long long* prof;  // 8 words of this block in RansArgs::prof, or NULL
+    int32_t n, cap;
 };
-struct Res {
-    int32_t tab_len, pay_len;
+struct Prep {
+    int32_t mode, stride, ent_off, tab_len, status;  // status 0 = tables ready, else a negative code
 };
 
-__device__ __attribute__((noinline)) Res run_o0(Blk B) {
-    CRAMGPU_DYN_LDS(smem);
+__device__ __attribute__((noinline)) int32_t stream_o0(Blk B, int32_t tab_len) {
+    const uint2* ent = reinterpret_cast<const uint2*>(lds.tab + 1024);
+    return encode_stream<MODE_O0>(B.src, B.n, ent, 256, B.slot + B.cap, B.cap - 9 - tab_len, B.prof);
+}
+__device__ __attribute__((noinline)) int32_t stream_o1_lds(Blk B, int32_t tab_len, int32_t stride, int32_t ent_off) {
+    const uint2* ent = reinterpret_cast<const uint2*>(lds.tab + ent_off);
+    return encode_stream<MODE_O1_LDS>(B.src, B.n, ent, stride, B.slot + B.cap, B.cap - 9 - tab_len, B.prof);
+}
+__device__ __attribute__((noinline)) int32_t stream_o1_global(Blk B, int32_t tab_len) {
+    const uint2* ent = reinterpret_cast<const uint2*>(B.gs + 256 * 1024);
+    return encode_stream<MODE_O1_GLOBAL>(B.src, B.n, ent, 256, B.slot + B.cap, B.cap - 9 - tab_len, B.prof);
+}
+
+// ---- phases 1 and 2, helper wave only ----
+__device__ __attribute__((noinline)) Prep prep_o0(Blk B) {
     const int l = lane_id();
-    EncFixedLds* L = reinterpret_cast<EncFixedLds*>(smem);
-    uint8_t* tab = smem + sizeof(EncFixedLds);
+    EncFixedLds* L = &lds;
+    uint8_t* tab = lds.tab;
     uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);    // 256 words
     uint2* ent0 = reinterpret_cast<uint2*>(tab + 1024);  // 256 x 8 B
     uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
     int R0 = 1;
-    while (R0 < 16 && (1024 + 2048 + 2 * R0 * 1024) <= B.tab_bytes) R0 <<= 1;
+    while (R0 < 16 && (1024 + 2048 + 2 * R0 * 1024) <= kTabBytes) R0 <<= 1;
     hist_o0(B.src, B.n, cnt0, rep0, R0);
     for (int i = l; i < 256; i += 64) L->syml[i] = (uint8_t)i;
-    __syncthreads();
-    Res r;
+    WSYNC();
+    Prep r{MODE_O0, 256, 1024, 0, 0};
     r.tab_len = tables_o0(cnt0, ent0, B.n, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
-    if (9 + r.tab_len + 16 > B.cap)
-        r.pay_len = CRAMGPU_E_INSUFFICIENT;
-    else
-        r.pay_len = encode_stream<MODE_O0>(B.src, B.n, ent0, 256, L, B.slot + B.cap, B.cap - 9 - r.tab_len);
+    if (9 + r.tab_len + 16 > B.cap) r.status = CRAMGPU_E_INSUFFICIENT;
     return r;
 }
 
-__device__ __attribute__((noinline)) Res run_o1_global(Blk B) {
-    CRAMGPU_DYN_LDS(smem);
+__device__ __attribute__((noinline)) Prep prep_o1_global(Blk B) {
     const int l = lane_id();
-    EncFixedLds* L = reinterpret_cast<EncFixedLds*>(smem);
+    EncFixedLds* L = &lds;
     uint32_t* cnt = reinterpret_cast<uint32_t*>(B.gs);
     uint2* ent = reinterpret_cast<uint2*>(B.gs + 256 * 1024);
     uint4* z = reinterpret_cast<uint4*>(B.gs);
@@ -600,42 +804,30 @@ __device__ __attribute__((noinline)) Res run_o1_global(Blk B) {
         L->dmap[i] = (uint8_t)i;
     }
     __threadfence();
-    __syncthreads();
-    Res r{0, 0};
-    const int stop = B.stop;  // debugging aid: leave the path after phase `stop`
-    if (stop == 1) r.pay_len = -51;
-    if (r.pay_len == 0) {
-        hist_o1(B.src, B.n, cnt, 256, L->dmap, nullptr, 1, 0, 0);
-        __threadfence();
-        __syncthreads();
-        if (stop == 2) r.pay_len = -52;
-    }
-    if (r.pay_len == 0) {
-        r.tab_len = tables_o1(cnt, ent, 256, 256, 256, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16, B.dbg, stop);
-        __threadfence();
-        __syncthreads();
-        if (r.tab_len < 0) r.pay_len = r.tab_len;
-    }
-    if (r.pay_len == 0) {
-        if (9 + r.tab_len + 16 > B.cap)
-            r.pay_len = CRAMGPU_E_INSUFFICIENT;
-        else
-            r.pay_len = encode_stream<MODE_O1_GLOBAL>(B.src, B.n, ent, 256, L, B.slot + B.cap, B.cap - 9 - r.tab_len, B.dbg);
-        if (stop == 7 && r.pay_len >= 0) r.pay_len = -57;
-    }
+    WSYNC();
+    hist_o1(B.src, B.n, cnt, 256, L->dmap, nullptr, 1, 0, 0);
+    __threadfence();
+    WSYNC();
+    Prep r{MODE_O1_GLOBAL, 256, 0, 0, 0};
+    r.tab_len = tables_o1(cnt, ent, 256, 256, 256, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
+    __threadfence();
+    WSYNC();
+    if (r.tab_len < 0)
+        r.status = r.tab_len;
+    else if (9 + r.tab_len + 16 > B.cap)
+        r.status = CRAMGPU_E_INSUFFICIENT;
     return r;
 }
 
-// returns pay_len == INT32_MIN when the alphabet does not fit the LDS table region
-__device__ __attribute__((noinline)) Res run_o1_lds(Blk B) {
-    CRAMGPU_DYN_LDS(smem);
+// status == INT32_MIN when the alphabet does not fit the LDS table region
+__device__ __attribute__((noinline)) Prep prep_o1_lds(Blk B) {
     const int l = lane_id();
-    EncFixedLds* L = reinterpret_cast<EncFixedLds*>(smem);
-    uint8_t* tab = smem + sizeof(EncFixedLds);
+    EncFixedLds* L = &lds;
+    uint8_t* tab = lds.tab;
     uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);
     uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
     int R0 = 1;
-    while (R0 < 16 && (1024 + 2048 + 2 * R0 * 1024) <= B.tab_bytes) R0 <<= 1;
+    while (R0 < 16 && (1024 + 2048 + 2 * R0 * 1024) <= kTabBytes) R0 <<= 1;
     hist_o0(B.src, B.n, cnt0, rep0, R0);
     // dense alphabet = present symbols plus 0 (context 0 always exists)
     uint32_t present = 0, mine = 0;
@@ -648,7 +840,7 @@ __device__ __attribute__((noinline)) Res run_o1_lds(Blk B) {
     }
     uint32_t nsym;
     uint32_t di = wave_excl_scan(mine, nsym);
-    __syncthreads();
+    WSYNC();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         int jj = l * 4 + k;
@@ -660,38 +852,41 @@ __device__ __attribute__((noinline)) Res run_o1_lds(Blk B) {
             L->dmap[jj] = 0;
         }
     }
-    __syncthreads();
+    WSYNC();
     const int ns = (int)nsym;
     const int stride = ns | 1;
     const int cells = ns * stride;
-    Res r{0, INT32_MIN};
-    if (12 * cells + 16 > B.tab_bytes) return r;
+    Prep r{MODE_O1_LDS, stride, 0, 0, INT32_MIN};
+    if (12 * cells + 16 > kTabBytes) return r;
     uint32_t* cnt = reinterpret_cast<uint32_t*>(tab);
     const int ent_off = (4 * cells + 15) & ~15;
     uint2* ent = reinterpret_cast<uint2*>(tab + ent_off);
     const int rep_off = ent_off + 8 * cells;
     const int rstride = cells | 1;
     int R = 1;
-    while (R < 32 && rep_off + 2 * R * rstride * 4 <= B.tab_bytes) R <<= 1;
+    while (R < 32 && rep_off + 2 * R * rstride * 4 <= kTabBytes) R <<= 1;
     uint32_t* rep = reinterpret_cast<uint32_t*>(tab + rep_off);
     for (int i = l; i < cells; i += 64) cnt[i] = 0;
-    __syncthreads();
+    WSYNC();
     hist_o1(B.src, B.n, cnt, stride, L->dmap, rep, R, rstride, cells);
+    r.ent_off = ent_off;
     r.tab_len = tables_o1(cnt, ent, ns, ns, stride, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
-    if (9 + r.tab_len + 16 > B.cap)
-        r.pay_len = CRAMGPU_E_INSUFFICIENT;
+    if (r.tab_len < 0)
+        r.status = r.tab_len;
     else
-        r.pay_len = encode_stream<MODE_O1_LDS>(B.src, B.n, ent, stride, L, B.slot + B.cap, B.cap - 9 - r.tab_len);
+        r.status = 9 + r.tab_len + 16 > B.cap ? CRAMGPU_E_INSUFFICIENT : 0;
     return r;
 }
 
 __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
+    EncFixedLds* L = &lds;
     const int l = lane_id();
+    const bool helper = wave_id() == 1;
     const cramgpu_block d = a.desc[b];
-    const int32_t n = d.in_len;
-    int order = d.order;
+    const int32_t n = UNIFORM(d.in_len);
+    int order = UNIFORM(d.order);
     uint8_t* slot = a.out + d.out_off;
-    const int32_t cap = d.out_cap;
+    const int32_t cap = UNIFORM(d.out_cap);
     int32_t result;
     int64_t pos = d.out_off;
     if (order != 0 && order != 1) {
@@ -704,26 +899,47 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
         if (n < 4) order = 0;  // RANS#compress L63-64
         uint8_t* tabdst = slot + 9;
         uint8_t* pend = slot + cap;
-        Blk B{a.in + d.in_off, slot, gs, a.rcp_tab, a.dbg, n, cap, a.tab_bytes, a.stop_phase};
-        Res r;
-        if (order == 0) {
-            r = run_o0(B);
-        } else {
-            r = run_o1_lds(B);
-            if (r.pay_len == INT32_MIN) r = run_o1_global(B);
+        Blk B{a.in + d.in_off, slot, gs, a.rcp_tab, a.prof ? a.prof + 8 * (size_t)b : nullptr, n, cap};
+        const long long t0 = a.prof ? clock64() : 0;
+        if (helper) {  // phases 1 and 2; the chain wave waits at the barrier below
+            Prep p;
+            if (order == 0) {
+                p = prep_o0(B);
+            } else {
+                p = prep_o1_lds(B);
+                if (p.status == INT32_MIN) p = prep_o1_global(B);
+            }
+            if (l == 0) {
+                L->mode = p.mode;
+                L->stride = p.stride;
+                L->ent_off = p.ent_off;
+                L->tab_len = p.tab_len;
+                L->status = p.status;
+            }
         }
-        const int32_t tab_len = r.tab_len, pay_len = r.pay_len;
-        if (l == 0) {
-            CRAMGPU_MARK(a.dbg, 0, 8);
-            CRAMGPU_MARK(a.dbg, 4, tab_len);
-            CRAMGPU_MARK(a.dbg, 5, pay_len);
+        __syncthreads();
+        const int32_t mode = UNIFORM(L->mode), stride = UNIFORM(L->stride), ent_off = UNIFORM(L->ent_off),
+                      tab_len = UNIFORM(L->tab_len);
+        int32_t pay_len = UNIFORM(L->status);
+        const long long t1 = a.prof ? clock64() : 0;
+        if (pay_len == 0) {
+            if (mode == MODE_O0)
+                pay_len = stream_o0(B, tab_len);
+            else if (mode == MODE_O1_LDS)
+                pay_len = stream_o1_lds(B, tab_len, stride, ent_off);
+            else
+                pay_len = stream_o1_global(B, tab_len);
+        }
+        if (!helper) return;  // the epilogue belongs to the helper wave (it holds the payload length)
+        if (a.prof && l == 0) {
+            B.prof[0] = (unsigned long long)(t1 - t0);
+            B.prof[1] = (unsigned long long)(clock64() - t1);
         }
         if (pay_len < 0) {
             result = pay_len;
         } else {
             // move the table in front of the payload (dst >= src: copy from the top down), then the 9-byte header
-            __threadfence_block();
-            __syncthreads();
+            WSYNC();
             uint8_t* dst = pend - pay_len - tab_len;
             if (dst != tabdst) {
                 for (int32_t hi = tab_len; hi > 0; hi -= 64) {
@@ -731,10 +947,10 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
                     uint8_t v = 0;
                     if (k >= 0) v = tabdst[k];
                     __threadfence_block();
-                    __syncthreads();
+                    WSYNC();
                     if (k >= 0) dst[k] = v;
                     __threadfence_block();
-                    __syncthreads();
+                    WSYNC();
                 }
             }
             uint8_t* h = dst - 9;
@@ -746,23 +962,22 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
             pos = (int64_t)(h - a.out);
         }
     }
-    if (l == 0) {
-        CRAMGPU_MARK(a.dbg, 0, 9);
+    if (helper && l == 0) {
         a.out_len[b] = result;
         a.out_pos[b] = pos;
-        CRAMGPU_MARK(a.dbg, 0, 10);
     }
 }
 
-__global__ __launch_bounds__(64) void rans_encode_kernel(RansArgs a) {
+__global__ __launch_bounds__(128) void rans_encode_kernel(RansArgs a) {
+    EncFixedLds* L = &lds;
     uint8_t* gs = a.gscratch + (size_t)blockIdx.x * ENC_GSCRATCH_BYTES;
     for (;;) {
-        uint32_t t = 0;
-        if (threadIdx.x == 0) t = atomicAdd(a.ticket, 1u);
-        t = __shfl(t, 0);
-        if (t >= (uint32_t)a.n_blocks) break;  // every wave reaches this: the queue only grows
-        encode_block(a, a.perm[t], gs);
+        if (threadIdx.x == 64) L->ticket = atomicAdd(a.ticket, 1u);
         __syncthreads();
+        const uint32_t t = (uint32_t)UNIFORM(L->ticket);
+        __syncthreads();  // both waves hold the ticket before the helper can draw the next one
+        if (t >= (uint32_t)a.n_blocks) break;  // every workgroup reaches this: the queue only grows
+        encode_block(a, a.perm[t], gs);
     }
 }
 
@@ -781,10 +996,11 @@ __global__ void rcp_init_kernel(uint32_t* tab) {
 
 }  // namespace
 
-size_t rans_encode_fixed_lds() { return sizeof(EncFixedLds); }
+size_t rans_encode_fixed_lds() { return 0; }  // the encoder's LDS is static
 
-hipError_t launch_rans_encode(const RansArgs& a, int n_waves, size_t lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(rans_encode_kernel, dim3(n_waves), dim3(64), lds_bytes, s, a);
+hipError_t launch_rans_encode(const RansArgs& a, int n_groups, size_t lds_bytes, hipStream_t s) {
+    (void)lds_bytes;
+    hipLaunchKernelGGL(rans_encode_kernel, dim3(n_groups), dim3(128), 0, s, a);
     return hipGetLastError();
 }
 

@@ -134,31 +134,83 @@ __global__ __launch_bounds__(256) void extract_kernel(cramgpu_reads R, const uin
     }
 }
 
-// exclusive scan of int32 counts into int64 offsets (off[n] = total), single workgroup
-__global__ __launch_bounds__(1024) void scan_kernel(const int32_t* counts, int32_t n, int64_t* off, int64_t* total) {
-    __shared__ int64_t part[1024];
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = min(n, t * per), hi = min(n, lo + per);
-    int64_t s = 0;
-    for (int i = lo; i < hi; i++) s += counts[i];
-    part[t] = s;
+// Exclusive scan of int32 counts into int64 offsets (off[n] = total) in three launches: per-tile sums, scan of the
+// tile sums by one workgroup, per-tile scan with the tile's base.  A tile is 256 threads x 16 consecutive counts.
+constexpr int kScanThreads = 256, kScanPer = 16, kScanTile = kScanThreads * kScanPer;
+
+__device__ __forceinline__ int64_t block_excl_scan_256(int64_t v, int64_t* sh, int64_t& total) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    int64_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) sh[w] = x;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int64_t v = t >= o ? part[t - o] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    int64_t base = 0;
+    for (int k = 0; k < w; k++) base += sh[k];
+    total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_tile_sums_kernel(const int32_t* counts, int32_t n, int64_t* tile_sum) {
+    __shared__ int64_t sh[4];
+    const int64_t lo = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPer;
+    int64_t s = 0;
+    if (lo + kScanPer <= n) {
+        const uint4* p = reinterpret_cast<const uint4*>(counts + lo);  // counts are >= 0
+#pragma unroll
+        for (int k = 0; k < kScanPer / 4; k++) {
+            const uint4 v = p[k];
+            s += (int64_t)v.x + v.y + v.z + v.w;
+        }
+    } else {
+        for (int64_t i = lo; i < n && i < lo + kScanPer; i++) s += counts[i];
     }
-    int64_t base = part[t] - s;
-    for (int i = lo; i < hi; i++) {
-        off[i] = base;
-        base += counts[i];
+    int64_t total;
+    (void)block_excl_scan_256(s, sh, total);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+
+// in-place exclusive scan of the tile sums by one workgroup; tile_sum[n_tiles] = grand total
+__global__ __launch_bounds__(kScanThreads) void scan_tiles_kernel(int64_t* tile_sum, int32_t n_tiles, int64_t* total_out) {
+    __shared__ int64_t sh[4];
+    int64_t carry = 0;
+    for (int32_t b0 = 0; b0 < n_tiles; b0 += kScanThreads) {
+        const int32_t i = b0 + (int32_t)threadIdx.x;
+        const int64_t v = i < n_tiles ? tile_sum[i] : 0;
+        int64_t total;
+        const int64_t e = block_excl_scan_256(v, sh, total);
+        if (i < n_tiles) tile_sum[i] = carry + e;
+        carry += total;
     }
-    if (t == 1023) {
-        off[n] = part[1023];
-        if (total) *total = part[1023];
+    if (threadIdx.x == 0) {
+        tile_sum[n_tiles] = carry;
+        if (total_out) *total_out = carry;
     }
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(const int32_t* counts, int32_t n, const int64_t* tile_base,
+                                                                  int32_t n_tiles, int64_t* off) {
+    __shared__ int64_t sh[4];
+    const int64_t lo = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPer;
+    int32_t c[kScanPer];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; k++) {
+        c[k] = lo + k < n ? counts[lo + k] : 0;
+        s += c[k];
+    }
+    int64_t total;
+    int64_t base = tile_base[blockIdx.x] + block_excl_scan_256(s, sh, total);
+#pragma unroll
+    for (int k = 0; k < kScanPer; k++) {
+        if (lo + k < n) off[lo + k] = base;
+        base += c[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) off[n] = tile_base[n_tiles];
 }
 
 // htsjdk!encoding/writer/Writer#write L139-261 -> SubstitutionMatrix#code: codes[cont][ref 5][base 256]
@@ -587,8 +639,18 @@ hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, c
     return hipGetLastError();
 }
 
-hipError_t launch_feature_scan(int32_t n_reads, const int32_t* d_counts, int64_t* d_off, int64_t* d_total, hipStream_t s) {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, d_counts, n_reads, d_off, d_total);
+size_t feature_scan_ws_elems(int32_t n_reads) { return (size_t)((n_reads + kScanTile - 1) / kScanTile) + 2; }
+
+hipError_t launch_feature_scan(int32_t n_reads, const int32_t* d_counts, int64_t* d_off, int64_t* d_total, int64_t* d_ws,
+                               hipStream_t s) {
+    const int32_t n_tiles = (n_reads + kScanTile - 1) / kScanTile;  // 0 tiles for n_reads == 0: off[0] = total = 0
+    if (n_tiles > 0)
+        hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(n_tiles), dim3(kScanThreads), 0, s, d_counts, n_reads, d_ws);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kScanThreads), 0, s, d_ws, n_tiles, d_total);
+    if (n_tiles > 0)
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(n_tiles), dim3(kScanThreads), 0, s, d_counts, n_reads, d_ws, n_tiles, d_off);
+    else
+        return hipMemcpyAsync(d_off, d_ws, sizeof(int64_t), hipMemcpyDeviceToDevice, s);
     return hipGetLastError();
 }
 

@@ -196,3 +196,4 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline long long clock64() { return 0; }
