@@ -188,10 +188,10 @@ int rans_run(cramgpu_ctx* c, bool encode, const uint8_t* d_in, uint8_t* d_out, c
                 if (blocks[i].in_len > blocks[big].in_len) big = i;
             const unsigned long long* r = h.data() + (size_t)big * 8;
             fprintf(stderr, "[cramgpu prof] largest block %d B: prep %llu cyc, stream %llu cyc, helper busy %llu, chain busy %llu, "
-                            "batches %llu (per step: stream %.1f, helper %.1f, chain %.1f of which record reads %.1f)\n",
-                    blocks[big].in_len, r[0], r[1], r[2], r[3], r[4], r[4] ? (double)r[1] / (16.0 * r[4]) : 0.0,
-                    r[4] ? (double)r[2] / (16.0 * r[4]) : 0.0, r[4] ? (double)r[3] / (16.0 * r[4]) : 0.0,
-                    r[4] ? (double)r[5] / (16.0 * r[4]) : 0.0);
+                            "batches %llu (per step: stream %.1f, helper %.1f, chain %.1f of which record reads %.1f; general half batches %llu)\n",
+                    blocks[big].in_len, r[0], r[1], r[2], r[3], r[4], r[4] ? (double)r[1] / (32.0 * r[4]) : 0.0,
+                    r[4] ? (double)r[2] / (32.0 * r[4]) : 0.0, r[4] ? (double)r[3] / (32.0 * r[4]) : 0.0,
+                    r[4] ? (double)r[5] / (32.0 * r[4]) : 0.0, r[6]);
         }
     } else {
         a.gscratch = c->dec_gs.p;

@@ -32,7 +32,9 @@
 
 namespace {
 
-constexpr int kSteps = 16;  // steps per batch: 16 steps x 4 states = 64 lanes of the helper wave
+constexpr int kSteps = 16;   // steps per half batch: 16 steps x 4 states = the 64 lanes of the helper wave
+constexpr int kHalves = 2;   // half batches between two barriers (amortises the barrier and the helper's fixed costs)
+constexpr int kBatch = kSteps * kHalves;
 
 constexpr int kRingBytes = 4096;  // input ring of the helper wave: 4 x 1 KiB (order 1) or 1 x 4 KiB (order 0)
 
@@ -45,11 +47,11 @@ struct alignas(16) EncFixed {
             uint32_t rowhdr[256];   // context-level header of each row: count | byte0 << 8 | byte1 << 16
         } p2;
         struct {                    // phase 3 (coding loop)
-            uint4 stage[2][64];     // [buffer][step*4 + state]: x_max, rcp_freq, bias, cmpl_freq | shift<<24 | small<<31
-            uint4 xs[2][4][4];      // [buffer][state][step/4]: state before each step of the batch
+            uint4 stage[2][kHalves][64];  // [buffer][half][step*4 + state]: x_max-1, rcp_freq, bias, cmpl_freq | shift<<24 | small<<31
+            uint4 xs[2][kHalves][4][4];   // [buffer][half][state][step/4]: state before each step of the batch
             uint8_t ring[kRingBytes];  // input bytes (dense symbol indices when the order-1 tables are in LDS)
             uint32_t fin[4];        // states after the last batch the chain ran
-            unsigned long long cbusy, cbusy2;  // profiling runs only: cycles the chain wave spent outside barriers
+            unsigned long long cbusy, cbusy2, cgen;  // profiling runs only: cycles the chain wave spent outside barriers
         } p3;
     };
     uint8_t dmap[256];    // byte value -> dense index
@@ -144,7 +146,7 @@ __device__ __forceinline__ uint2 pack_symbol(int32_t freq, uint32_t start, const
 __device__ __forceinline__ uint4 expand_symbol(uint2 e) {
     const uint32_t f = e.y & 4095u;
     uint4 A;
-    A.x = f << 19;                 // x_max = ((L >> 12) << 8) * freq
+    A.x = (f << 19) - 1u;          // x_max - 1 with x_max = ((L >> 12) << 8) * freq: renormalise iff x > x_max - 1
     A.y = e.x;                     // rcp_freq
     A.z = (e.y >> 12) & 8191u;     // bias
     // cmpl_freq in the low 24 bits (all a 24-bit multiply reads), rcp_shift-32 in bits 24..28 (all a shift reads of
@@ -156,16 +158,54 @@ __device__ __forceinline__ uint4 expand_symbol(uint2 e) {
 // ---------------------------------------------------------------------------------------------------------
 // phase 1: histograms
 // ---------------------------------------------------------------------------------------------------------
-// order-0 counts of src[0..n) into cnt[256] using R lane-replicated LDS histograms at rep (R*256 words)
-__device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* rep, int R) {
+// The histogram passes read the block in 16-byte units, unit k of a sweep at byte (sweep * 64 + lane) * 16.  A sweep is
+// ~200-400 cycles of LDS atomics against ~1-2 us of load latency, so four sweeps are kept in flight in four fixed
+// registers (a rotating register would make the compiler wait at the copy).  F(v, i, prev): unit v at byte i, prev =
+// the byte before it (0 at i == 0; only loaded when WITH_PREV).
+template <bool WITH_PREV, class F>
+__device__ __forceinline__ void for_each_unit(const uint8_t* src, int32_t n16, int l, F f) {
+    constexpr int32_t kSweep = 64 * 16;
+    uint4 v[4];
+    uint32_t pv[4];
+    int32_t i = l * 16;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int32_t p = i + k * kSweep;
+        v[k] = make_uint4(0, 0, 0, 0);
+        pv[k] = 0;
+        if (p < n16) {
+            v[k] = *reinterpret_cast<const uint4*>(src + p);
+            if (WITH_PREV && p > 0) pv[k] = src[p - 1];
+        }
+    }
+    for (; i < n16; i += 4 * kSweep) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int32_t p = i + k * kSweep;
+            if (p < n16) f(v[k], p, pv[k]);
+            const int32_t pn = p + 4 * kSweep;
+            if (pn < n16) {
+                v[k] = *reinterpret_cast<const uint4*>(src + pn);
+                if (WITH_PREV) pv[k] = src[pn - 1];
+            }
+        }
+    }
+}
+
+// order-0 counts of src[0..n) into cnt[256] using kRep0 lane-replicated LDS histograms at rep.  The replicas are 257
+// words apart: at 256 every replica would put a symbol in the same LDS bank and the lanes that see the same symbol
+// (most of them, in a quality stream) would serialise exactly as without replicas.
+constexpr int kRep0 = 16, kRep0Stride = 257;
+static_assert(1024 + 2048 + kRep0 * kRep0Stride * 4 <= kTabBytes, "order-0 replicas must fit the table region");
+__device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* rep) {
     const int l = lane_id();
-    for (int i = l; i < R * 256; i += 64) rep[i] = 0;
+    constexpr int R = kRep0;
+    for (int i = l; i < R * kRep0Stride; i += 64) rep[i] = 0;
     WSYNC();
-    uint32_t* my = rep + (l & (R - 1)) * 256;
+    uint32_t* my = rep + (l & (R - 1)) * kRep0Stride;
     const int32_t n16 = n & ~15;
-    for (int32_t i = l * 16; i < n16; i += 64 * 16) {
-        uint4 v = *reinterpret_cast<const uint4*>(src + i);
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    for_each_unit<false>(src, n16, l, [&](const uint4& v, int32_t, uint32_t) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             atomicAdd(&my[w[k] & 255u], 1u);
@@ -173,12 +213,12 @@ __device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* 
             atomicAdd(&my[(w[k] >> 16) & 255u], 1u);
             atomicAdd(&my[w[k] >> 24], 1u);
         }
-    }
+    });
     if (n16 + l < n) atomicAdd(&my[src[n16 + l]], 1u);
     WSYNC();
     for (int j = l; j < 256; j += 64) {
         uint32_t s = 0;
-        for (int r = 0; r < R; r++) s += rep[r * 256 + j];
+        for (int r = 0; r < R; r++) s += rep[r * kRep0Stride + j];
         cnt[j] = s;
     }
     WSYNC();
@@ -198,11 +238,9 @@ __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n,
     }
     WSYNC();
     const int32_t n16 = n & ~15;
-    for (int32_t i = l * 16; i < n16; i += 64 * 16) {
-        uint4 v = *reinterpret_cast<const uint4*>(src + i);
-        uint32_t prev = i ? src[i - 1] : 0u;
+    for_each_unit<true>(src, n16, l, [&](const uint4& v, int32_t, uint32_t prev) {
         uint32_t row = (uint32_t)dmap[prev] * (uint32_t)stride;
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
 #pragma unroll
@@ -213,7 +251,7 @@ __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n,
                 row = col * (uint32_t)stride;
             }
         }
-    }
+    });
     if (n16 + l < n) {
         int32_t i = n16 + l;
         uint32_t prev = i ? src[i - 1] : 0u, c = src[i];
@@ -482,7 +520,8 @@ __device__ __forceinline__ int ring_addr(int32_t pos, int j) {
     return j * (kRingBytes / 4) + (pos & (kRingBytes / 4 - 1));
 }
 
-constexpr int kChunkSteps = 256;  // steps per input chunk = 16 batches
+constexpr int kChunkSteps = 256;  // steps per input chunk = 8 batches
+constexpr int kChunkBatches = kChunkSteps / kBatch;
 
 // One input chunk = the positions steps [256c, 256c + 256) touch, as 16-byte units: order 0 one run of <= 65 units,
 // order 1 four runs (one per quarter) of <= 18 units.  A lane owns up to two units.
@@ -540,71 +579,120 @@ __device__ __forceinline__ void chunk_store(const ChunkRegs& R, uint8_t* ring, c
 }
 
 // Helper lane l owns step (l >> 2) and state 3 - (l & 3) of a batch, so that lane order is the reference's emission
-// order.  lookup: ring -> packed symbol (valid = the pair is active).
+// order.  Its input position falls by a constant from batch to batch, and its pair is active for a contiguous range of
+// steps, so the per-batch bookkeeping is a handful of adds and compares.
+struct Cursor {
+    int32_t pos;      // input position of the lane's pair in the batch being looked up
+    uint32_t u;       // its step
+    uint32_t ulo, ucnt;  // active iff u - ulo < ucnt
+    uint32_t ufirst;  // order 1: step at which the pair sits on the first byte of its quarter (context 0)
+    int ringbase;
+};
 template <int MODE>
-__device__ __forceinline__ uint2 lookup_entry(const Geo& g, int32_t u, int j, const uint8_t* ring, const uint2* ent, int stride,
-                                              bool& act) {
-    const int32_t pos = pos_of<MODE>(g, u, j);
-    act = active_of<MODE>(g, u, j, pos);
-    uint2 e = make_uint2(0u, 0u);
-    if (act) {
-        const uint32_t sym = ring[ring_addr<MODE>(pos, j)];
-        if (MODE == MODE_O0) {
-            e = ent[sym];
-        } else {
-            const bool first = pos == j * g.q;  // first byte of the quarter: context 0
-            const uint32_t ctx = first ? 0u : ring[ring_addr<MODE>(pos - 1, j)];
-            e = ent[ctx * (uint32_t)stride + sym];
-        }
+__device__ __forceinline__ Cursor cursor_init(const Geo& g, int t, int j) {  // t = step within the batch
+    Cursor c;
+    c.u = (uint32_t)t;
+    c.pos = pos_of<MODE>(g, t, j);
+    if (MODE == MODE_O0) {
+        c.ulo = j < (g.n & 3) ? 0u : 1u;  // step 0 is the n&3 tail
+        c.ufirst = 0xFFFFFFFFu;
+        c.ringbase = 0;
+    } else {
+        c.ulo = j == 3 ? 0u : (uint32_t)g.rem;
+        c.ufirst = (uint32_t)(pos_of<MODE>(g, 0, j) - j * g.q);
+        c.ringbase = j * (kRingBytes / 4);
     }
-    return e;
+    c.ucnt = (uint32_t)g.U > c.ulo ? (uint32_t)g.U - c.ulo : 0u;
+    return c;
+}
+template <int MODE>
+__device__ __forceinline__ void cursor_next(Cursor& c) {
+    c.u += kBatch;
+    c.pos -= MODE == MODE_O0 ? 4 * kBatch : kBatch;
+}
+// ring -> packed symbol of the cursor's pair (reads are unconditional: a stale ring byte is a valid table index)
+template <int MODE>
+__device__ __forceinline__ uint2 lookup_entry(const Cursor& c, const uint8_t* ring, const uint2* ent, int stride, bool& act) {
+    constexpr int mask = MODE == MODE_O0 ? kRingBytes - 1 : kRingBytes / 4 - 1;
+    act = c.u - c.ulo < c.ucnt;
+    const uint32_t sym = ring[c.ringbase + (c.pos & mask)];
+    if (MODE == MODE_O0) return ent[sym];
+    uint32_t ctx = ring[c.ringbase + ((c.pos - 1) & mask)];
+    if (c.u == c.ufirst) ctx = 0u;
+    const uint32_t idx = ctx * (uint32_t)stride + sym;
+    return ent[act ? idx : 0u];  // an inactive pair may hold a stale ring byte: no stray table reads
 }
 
 // Encoding#RansEncPutSymbol L46-71 for 16 steps of one state (chain wave, lanes 0-3 = states 0-3); the state before
-// every step is logged to xs[step] for the helper wave.
+// every step is logged to xs[step] for the helper wave.  The renormalisation test is arithmetic — the sign of
+// (x_max - 1) - x selects a byte shift (v_alignbyte) — because a compare + select through VCC needs two idle issue
+// slots between them on gfx950 (scripts/ubench/seq_bench.hip: 14.0 vs 18.3 cycles).
 // GENERAL: the batch holds symbols with freq < 16, whose first renormalisation byte is certain (x >= L > x_max).
+__device__ __forceinline__ uint32_t shr_bytes(uint32_t x, uint32_t nbytes) {
+#ifdef HIP_SIM
+    return x >> (8u * (nbytes & 3u));
+#else
+    return __builtin_amdgcn_alignbyte(0u, x, nbytes);
+#endif
+}
 template <bool GENERAL>
-__device__ __forceinline__ uint32_t chain_steps(uint32_t x, const uint4 (&P)[kSteps], uint32_t* xs) {
+__device__ __forceinline__ uint32_t chain_steps(uint32_t x, const uint4 (&P)[kSteps], uint4* xs) {
+    uint32_t xl[kSteps];
 #pragma unroll
     for (int tt = 0; tt < kSteps; tt++) {
-        xs[tt] = x;
-        if (GENERAL) x = (int32_t)P[tt].w < 0 ? x >> 8 : x;
-        const uint32_t xr = x >= P[tt].x ? x >> 8 : x;
+        xl[tt] = x;
+        if (GENERAL) x = shr_bytes(x, P[tt].w >> 31);
+        const uint32_t xr = shr_bytes(x, (P[tt].x - x) >> 31);
         const uint32_t qq = __umulhi(xr, P[tt].y) >> ((P[tt].w >> 24) & 31u);  // qq < 2^19, cmpl_freq < 2^12
         x = xr + P[tt].z + __umul24(qq, P[tt].w);
     }
+#pragma unroll
+    for (int k = 0; k < kSteps / 4; k++) xs[k] = make_uint4(xl[4 * k], xl[4 * k + 1], xl[4 * k + 2], xl[4 * k + 3]);
     return x;
 }
 
 #ifndef HIP_SIM
-// The same steps (freq >= 16 only) scheduled by hand: 8 issue slots per step.  A lone wave issues one instruction per
-// ~4.4 cycles and v_cndmask needs two other instructions between it and the v_cmp that wrote VCC; the shift and the
-// log write fill those slots (the compiler pads them with s_nop).  The shift count is byte 3 of the record's last word
+// The same steps as straight-line assembly, 7 instructions per step (9 in a general half batch), every state in its own
+// register so that the log leaves as one 16-byte LDS write per four steps (an LDS instruction costs the issuing
+// wave 8-20 cycles, three to four times a vector instruction).  The shift count is byte 3 of the record's last word
 // (SDWA), the 24-bit multiply ignores that byte.
-#define RANS_STEP(K)                                                                                          \
-    "v_cmp_lt_u32 vcc, %[x], %[a" #K "]\n\t"                                                                  \
-    "v_lshrrev_b32 %[t], 8, %[x]\n\t"                                                                         \
-    "ds_write_b32 %[adr], %[x] offset:%c[o" #K "]\n\t"                                                        \
-    "v_cndmask_b32 %[x], %[t], %[x], vcc\n\t"                                                                 \
-    "v_mul_hi_u32 %[m], %[x], %[b" #K "]\n\t"                                                                 \
+#define RANS_CORE(XI, XO, K)                                                                                  \
+    "v_sub_u32 %[t], %[a" #K "], %[" #XI "]\n\t"                                                              \
+    "v_lshrrev_b32 %[t], 31, %[t]\n\t"                                                                        \
+    "v_alignbyte_b32 %[r], 0, %[" #XI "], %[t]\n\t"                                                           \
+    "v_mul_hi_u32 %[m], %[r], %[b" #K "]\n\t"                                                                 \
     "v_lshrrev_b32_sdwa %[m], %[d" #K "], %[m] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t" \
     "v_mul_u32_u24 %[m], %[m], %[d" #K "]\n\t"                                                                \
-    "v_add3_u32 %[x], %[x], %[c" #K "], %[m]\n\t"
-__device__ __forceinline__ uint32_t chain_steps_fast(uint32_t x, const uint4 (&P)[kSteps], uint32_t xs_lds) {
+    "v_add3_u32 %[" #XO "], %[r], %[c" #K "], %[m]\n\t"
+#define RANS_STEP(XI, XO, K) RANS_CORE(XI, XO, K)
+// general step: a record with bit 31 set (freq < 16) first drops the byte that is certain to leave
+#define RANS_STEP_G(XI, XO, K)                                                                                \
+    "v_lshrrev_b32 %[t], 31, %[d" #K "]\n\t"                                                                  \
+    "v_alignbyte_b32 %[p], 0, %[" #XI "], %[t]\n\t" RANS_CORE(p, XO, K)
+#define RANS_OPERANDS                                                                                          \
+    [x0] "v"(x0), [a0] "v"(P[g].x), [b0] "v"(P[g].y), [c0] "v"(P[g].z), [d0] "v"(P[g].w), [a1] "v"(P[g + 1].x),     \
+        [b1] "v"(P[g + 1].y), [c1] "v"(P[g + 1].z), [d1] "v"(P[g + 1].w), [a2] "v"(P[g + 2].x), [b2] "v"(P[g + 2].y), \
+        [c2] "v"(P[g + 2].z), [d2] "v"(P[g + 2].w), [a3] "v"(P[g + 3].x), [b3] "v"(P[g + 3].y), [c3] "v"(P[g + 3].z), \
+        [d3] "v"(P[g + 3].w)
+template <bool GENERAL>
+__device__ __forceinline__ uint32_t chain_steps_asm(uint32_t x0, const uint4 (&P)[kSteps], uint4* xs) {
 #pragma unroll
     for (int g = 0; g < kSteps; g += 4) {
-        uint32_t t, m;
-        asm volatile(RANS_STEP(0) RANS_STEP(1) RANS_STEP(2) RANS_STEP(3)
-                     : [x] "+v"(x), [t] "=&v"(t), [m] "=&v"(m)
-                     : [adr] "v"(xs_lds), [o0] "n"(0), [o1] "n"(4), [o2] "n"(8), [o3] "n"(12),
-                       [a0] "v"(P[g].x), [b0] "v"(P[g].y), [c0] "v"(P[g].z), [d0] "v"(P[g].w),
-                       [a1] "v"(P[g + 1].x), [b1] "v"(P[g + 1].y), [c1] "v"(P[g + 1].z), [d1] "v"(P[g + 1].w),
-                       [a2] "v"(P[g + 2].x), [b2] "v"(P[g + 2].y), [c2] "v"(P[g + 2].z), [d2] "v"(P[g + 2].w),
-                       [a3] "v"(P[g + 3].x), [b3] "v"(P[g + 3].y), [c3] "v"(P[g + 3].z), [d3] "v"(P[g + 3].w)
-                     : "vcc", "memory");
-        xs_lds += 16;
+        uint32_t x1, x2, x3, x4, t, r, m, p;
+        if (GENERAL)
+            asm volatile(RANS_STEP_G(x0, x1, 0) RANS_STEP_G(x1, x2, 1) RANS_STEP_G(x2, x3, 2) RANS_STEP_G(x3, x4, 3)
+                         : [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [t] "=&v"(t), [r] "=&v"(r),
+                           [m] "=&v"(m), [p] "=&v"(p)
+                         : RANS_OPERANDS);
+        else
+            asm volatile(RANS_STEP(x0, x1, 0) RANS_STEP(x1, x2, 1) RANS_STEP(x2, x3, 2) RANS_STEP(x3, x4, 3)
+                         : [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [t] "=&v"(t), [r] "=&v"(r),
+                           [m] "=&v"(m)
+                         : RANS_OPERANDS);
+        xs[g >> 2] = make_uint4(x0, x1, x2, x3);
+        x0 = x4;
     }
-    return x;
+    return x0;
 }
 #endif
 
@@ -628,13 +716,22 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
     g.q = n >> 2;
     g.rem = MODE == MODE_O0 ? 0 : n - 4 * g.q;
     g.U = MODE == MODE_O0 ? g.q + 1 : g.q + g.rem;
-    const int32_t nbatch = (g.U + kSteps - 1) / kSteps;
+    const int32_t nbatch = (g.U + kBatch - 1) / kBatch;
     const int32_t limit = room - 16;
-    const uint4 ident = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);  // identity step for inactive (step, state) pairs
+    const uint4 ident = make_uint4(0x7FFFFFFFu, 0u, 0u, 0u);  // identity step for inactive (step, state) pairs (x < 2^31)
     uint32_t x = RANS_BYTE_L;  // chain wave
-    uint4 A0 = ident, A1 = ident;  // helper wave: records of batch i and batch i-1
-    uint2 e2 = make_uint2(0u, 0u);
-    bool act2 = false;             // looked-up symbol of batch i+2 (then i+1)
+    // helper wave, per half batch: records of batch i and batch i-1, looked-up symbol of batch i+2 (then i+1)
+    uint4 A0[kHalves], A1[kHalves];
+    uint2 e2[kHalves];
+    bool act2[kHalves];
+    Cursor cur[kHalves];
+#pragma unroll
+    for (int h = 0; h < kHalves; h++) {
+        A0[h] = A1[h] = ident;
+        e2[h] = make_uint2(0u, 0u);
+        act2[h] = false;
+        cur[h] = cursor_init<MODE>(g, h * kSteps + t, j);
+    }
     ChunkRegs CR;
     int32_t run = 0;
     bool failed = false;
@@ -643,76 +740,98 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
         chunk_store<MODE>(CR, L->p3.ring, L->dmap);
         chunk_load<MODE>(src, g, 1, l, CR);
         WSYNC();
-        bool act0;
-        const uint2 e0 = lookup_entry<MODE>(g, t, j, L->p3.ring, ent, stride, act0);
-        A0 = act0 ? expand_symbol(e0) : ident;
-        const unsigned long long sm = __ballot((int32_t)A0.w < 0);
-        uint4 W = A0;
-        if (t == 0 && sm != 0) W.w |= 0x40000000u;  // bit 30 of the step-0 records: the batch needs the general chain
-        L->p3.stage[0][slot] = W;
-        e2 = lookup_entry<MODE>(g, kSteps + t, j, L->p3.ring, ent, stride, act2);
+#pragma unroll
+        for (int h = 0; h < kHalves; h++) {
+            bool act0;
+            const uint2 e0 = lookup_entry<MODE>(cur[h], L->p3.ring, ent, stride, act0);
+            cursor_next<MODE>(cur[h]);
+            A0[h] = act0 ? expand_symbol(e0) : ident;
+            const unsigned long long sm = __ballot((int32_t)A0[h].w < 0);
+            uint4 W = A0[h];
+            if (t == 0 && sm != 0) W.w |= 0x40000000u;  // bit 30 of the step-0 records: this half needs the general chain
+            L->p3.stage[0][h][slot] = W;
+        }
+#pragma unroll
+        for (int h = 0; h < kHalves; h++) {
+            e2[h] = lookup_entry<MODE>(cur[h], L->p3.ring, ent, stride, act2[h]);
+            cursor_next<MODE>(cur[h]);
+        }
     }
     pair_barrier();
 #ifndef HIP_SIM
     if (!helper) __builtin_amdgcn_s_setprio(3);  // the chain wave is the critical path of the block
 #endif
-    unsigned long long busy = 0, busy2 = 0;
+    unsigned long long busy = 0, busy2 = 0, ngen = 0;
     for (int32_t i = 0; i <= nbatch; i++) {
         const int buf = i & 1;
         const long long tb = prof ? clock64() : 0;
         if (!helper) {
             if (i < nbatch && l < 4) {
-                uint4 P[kSteps];
 #pragma unroll
-                for (int tt = 0; tt < kSteps; tt++) P[tt] = L->p3.stage[buf][tt * 4 + l];
-                uint32_t* xs = reinterpret_cast<uint32_t*>(&L->p3.xs[buf][l][0]);
-                const bool general = (UNIFORM(P[0].w) & 0x40000000u) != 0;
-                if (prof) busy2 += (unsigned long long)(clock64() - tb);
-                if (general) {
-                    x = chain_steps<true>(x, P, xs);
-                } else {
+                for (int h = 0; h < kHalves; h++) {
+                    uint4 P[kSteps];
+#pragma unroll
+                    for (int tt = 0; tt < kSteps; tt++) P[tt] = L->p3.stage[buf][h][tt * 4 + l];
+                    uint4* xs = &L->p3.xs[buf][h][l][0];
+                    const bool general = (UNIFORM(P[0].w) & 0x40000000u) != 0;
+                    if (prof && h == 0) busy2 += (unsigned long long)(clock64() - tb);
+                    if (prof && general) ngen++;
 #ifdef HIP_SIM
-                    x = chain_steps<false>(x, P, xs);
+                    x = general ? chain_steps<true>(x, P, xs) : chain_steps<false>(x, P, xs);
 #else
-                    x = chain_steps_fast(x, P, (uint32_t)(uintptr_t)xs);  // low half of a generic LDS address = LDS offset
+                    x = general ? chain_steps_asm<true>(x, P, xs) : chain_steps_asm<false>(x, P, xs);
 #endif
                 }
                 L->p3.fin[l] = x;
             }
         } else {
-            if (i >= 1) {
-                // bytes of batch i-1 in the reference's emission order (state 3,2,1,0 per step = lane order)
-                const uint32_t xv = reinterpret_cast<const uint32_t*>(&L->p3.xs[buf ^ 1][0][0])[j * kSteps + t];
-                const bool small = (int32_t)A1.w < 0;
-                const uint32_t x1 = small ? xv >> 8 : xv;
-                const int nb = (small ? 1 : 0) + (x1 >= A1.x ? 1 : 0);
+            // the log of batch i-1 (garbage in iteration 0, masked below)
+            uint32_t xv[kHalves];
+#pragma unroll
+            for (int h = 0; h < kHalves; h++)
+                xv[h] = reinterpret_cast<const uint32_t*>(&L->p3.xs[buf ^ 1][h][0][0])[j * kSteps + t];
+            // batch i+1: expand the symbols looked up one iteration ago
+            uint4 An[kHalves];
+#pragma unroll
+            for (int h = 0; h < kHalves; h++) {
+                An[h] = act2[h] ? expand_symbol(e2[h]) : ident;
+                const unsigned long long sm = __ballot((int32_t)An[h].w < 0);
+                uint4 W = An[h];
+                if (t == 0 && sm != 0) W.w |= 0x40000000u;
+                L->p3.stage[buf ^ 1][h][slot] = W;
+            }
+            // input ring: chunk c is needed from iteration 8c - 2 on; it is written at 8c - 4 from the registers that
+            // were loaded at 8c - 12, and the next chunk's loads are issued
+            if ((i & (kChunkBatches - 1)) == kChunkBatches / 2) {
+                chunk_store<MODE>(CR, L->p3.ring, L->dmap);
+                chunk_load<MODE>(src, g, (i + kChunkBatches / 2) / kChunkBatches + 1, l, CR);
+                WSYNC();
+            }
+            // batch i+2: symbol lookup (the table reads land while this wave is at the barrier)
+#pragma unroll
+            for (int h = 0; h < kHalves; h++) {
+                e2[h] = lookup_entry<MODE>(cur[h], L->p3.ring, ent, stride, act2[h]);
+                cursor_next<MODE>(cur[h]);
+            }
+            // bytes of batch i-1 in the reference's emission order (state 3,2,1,0 per step = lane order)
+#pragma unroll
+            for (int h = 0; h < kHalves; h++) {
+                const bool small = (int32_t)A1[h].w < 0;
+                const uint32_t x1 = small ? xv[h] >> 8 : xv[h];
+                int nb = (small ? 1 : 0) + (x1 > A1[h].x ? 1 : 0);
+                if (i == 0) nb = 0;
                 const unsigned long long m1 = __ballot(nb >= 1), m2 = __ballot(nb == 2);
                 const int32_t tot = __popcll(m1) + __popcll(m2);
                 if (run + tot > limit) failed = true;
                 if (!failed) {
                     const int32_t idx = run + (int32_t)(mbcnt(m1) + mbcnt(m2));
-                    if (nb >= 1) pend[-1 - idx] = (uint8_t)xv;
-                    if (nb == 2) pend[-2 - idx] = (uint8_t)(xv >> 8);
+                    if (nb >= 1) pend[-1 - idx] = (uint8_t)xv[h];
+                    if (nb == 2) pend[-2 - idx] = (uint8_t)(xv[h] >> 8);
                     run += tot;
                 }
+                A1[h] = A0[h];
+                A0[h] = An[h];
             }
-            // batch i+1: expand the symbol looked up one iteration ago
-            const uint4 An = act2 ? expand_symbol(e2) : ident;
-            const unsigned long long sm = __ballot((int32_t)An.w < 0);
-            uint4 W = An;
-            if (t == 0 && sm != 0) W.w |= 0x40000000u;
-            L->p3.stage[buf ^ 1][slot] = W;
-            A1 = A0;
-            A0 = An;
-            // input ring: chunk c is needed from iteration 16c - 2 on; it is written at 16c - 8 from the registers that
-            // were loaded at 16c - 24, and the next chunk's loads are issued
-            if ((i & 15) == 8) {
-                chunk_store<MODE>(CR, L->p3.ring, L->dmap);
-                chunk_load<MODE>(src, g, (i + 8) / 16 + 1, l, CR);
-                WSYNC();
-            }
-            // batch i+2: symbol lookup
-            e2 = lookup_entry<MODE>(g, (i + 2) * kSteps + t, j, L->p3.ring, ent, stride, act2);
         }
         if (prof) busy += (unsigned long long)(clock64() - tb);
         pair_barrier();
@@ -724,12 +843,14 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
         if (!helper && l == 0) {
             L->p3.cbusy = busy;
             L->p3.cbusy2 = busy2;
+            L->p3.cgen = ngen;
         }
         pair_barrier();
         if (helper && l == 0) {
             prof[2] = busy;
             prof[3] = L->p3.cbusy;
             prof[5] = L->p3.cbusy2;
+            prof[6] = L->p3.cgen;
             prof[4] = (unsigned long long)nbatch;
         }
     }
@@ -781,9 +902,7 @@ __device__ __attribute__((noinline)) Prep prep_o0(Blk B) {
     uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);    // 256 words
     uint2* ent0 = reinterpret_cast<uint2*>(tab + 1024);  // 256 x 8 B
     uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
-    int R0 = 1;
-    while (R0 < 16 && (1024 + 2048 + 2 * R0 * 1024) <= kTabBytes) R0 <<= 1;
-    hist_o0(B.src, B.n, cnt0, rep0, R0);
+    hist_o0(B.src, B.n, cnt0, rep0);
     for (int i = l; i < 256; i += 64) L->syml[i] = (uint8_t)i;
     WSYNC();
     Prep r{MODE_O0, 256, 1024, 0, 0};
@@ -826,9 +945,7 @@ __device__ __attribute__((noinline)) Prep prep_o1_lds(Blk B) {
     uint8_t* tab = lds.tab;
     uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);
     uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
-    int R0 = 1;
-    while (R0 < 16 && (1024 + 2048 + 2 * R0 * 1024) <= kTabBytes) R0 <<= 1;
-    hist_o0(B.src, B.n, cnt0, rep0, R0);
+    hist_o0(B.src, B.n, cnt0, rep0);
     // dense alphabet = present symbols plus 0 (context 0 always exists)
     uint32_t present = 0, mine = 0;
 #pragma unroll

@@ -9,8 +9,15 @@ from cramtools_amd import _lib, external_compression as xc, synth
 
 def main():
     eng = xc.Engine(0)
+    import bench
     q = synth.markov_quals(1500000, 2)
-    for nb in (1, 1000):
+    # the bench's own quality stream (first container), to compare with the plain markov stream
+    from cramtools_amd import synth_torch
+    ref = synth_torch.reference(640000, device="cuda:0")
+    rs = synth_torch.make_reads(10000, ref, read_len=150, seed=1, qual_seed=2, err_seed=3)
+    qb = rs.quals[:1500000].cpu().numpy()
+    print("alphabet markov %d, bench %d" % (len(set(q.tolist())), len(set(qb.tolist()))))
+    for q, nb in ((q, 1), (qb, 1), (qb, 1000)):
         n = q.size
         lens, orders = [n] * nb, [1] * nb
         blocks, in_bytes, out_bytes = xc.Engine.plan_encode(lens, orders)
