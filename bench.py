@@ -3,7 +3,7 @@
 
 One "step" = one pass of the encode hot path over the whole synthetic read set resident in HBM:
   K3  reference-diff feature extraction over every read (two passes + scan, substitution histogram),
-  F3  substitution matrices (host, 25 numbers per container) + code assignment,
+  F3  substitution matrices + code assignment (device, per container),
   K1  rANS order-0 / order-1 encode of every external block of every container (QS, BA, BF, CF, NS, RG, RL, TS
       order 1; AP, RI order 0 — the fixed series->codec map of CompressionHeaderFactory#build L82-124),
   gather of the compressed streams into one dense arena (what would cross PCIe).
@@ -138,6 +138,7 @@ class Step:
         self.d_pack_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
         self.feats = rec.FeatureBatch(dev, w["reads"].n, w["feat_cap"])
         self.hist = torch.zeros(w["n_cont"] * 25, dtype=torch.int64, device=dev)
+        self.mats = torch.zeros(w["n_cont"] * 5, dtype=torch.uint8, device=dev)
         self.fac = rec.Sam2CramRecordFactory(eng)
         self.fac.set_ref_bases(w["ref"])
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -153,11 +154,7 @@ class Step:
         n = _lib.check(L.cramgpu_extract_features_dev(self.eng.handle, C.byref(rs_), w["ref"].data_ptr(), C.byref(fs_),
                                                       self.hist.data_ptr(), s))
         self.feats.count = int(n)
-        hist = self.hist.cpu().numpy().reshape(w["n_cont"], 25)
-        mats = np.zeros((w["n_cont"], 5), np.uint8)
-        for c in range(w["n_cont"]):
-            L.cramgpu_substitution_matrix(hist[c].ctypes.data, mats[c].ctypes.data)
-        self.fac.assign_codes(reads, self.feats, mats)
+        self.fac.matrices_and_codes(reads, self.feats, self.hist, self.mats)  # F3 on the device, stream-ordered
         # K1 + gather
         if timed:
             self.ev[0].record()

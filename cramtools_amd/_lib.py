@@ -85,6 +85,7 @@ SYMBOLS = {
     "cramgpu_extract_features_dev": (I64, [P, P, P, P, P, P]),
     "cramgpu_substitution_matrix": (None, [P, P]),
     "cramgpu_assign_codes_dev": (I32, [P, I32, P, I32, P, P, P]),
+    "cramgpu_matrices_assign_codes_dev": (I32, [P, I32, P, I32, P, P, P, P]),
     "cramgpu_restore_bases_dev": (I32, [P, I32, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P]),
     "cramgpu_restore_quals_dev": (I32, [P, I32, P, P, P, U8, P, P, P, P]),
     "cramgpu_parse_policies": (I32, [C.c_char_p, P, I32]),

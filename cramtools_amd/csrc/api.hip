@@ -111,7 +111,7 @@ struct cramgpu_ctx {
     DevBuf<int64_t> d_total, d_scan_ws;
     PinBuf<int64_t> h_total;
     DevBuf<uint8_t> d_small;   // matrix tables, policies
-    DevBuf<uint8_t> d_maskws;
+    DevBuf<uint8_t> d_maskws, d_codes25;
     DevBuf<unsigned long long> d_prof;  // CRAMGPU_PROF=1
     bool prof_on = false;
 };
@@ -276,7 +276,7 @@ void cramgpu_close(cramgpu_ctx* c) {
     c->h_desc.release(); c->h_perm.release(); c->d_desc.release(); c->d_perm.release();
     c->d_in.release(); c->d_out.release(); c->d_pack.release(); c->d_len.release(); c->d_pos.release();
     c->d_off.release(); c->d_err.release(); c->h_stage.release(); c->h_len.release(); c->h_off.release();
-    c->d_counts.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_small.release(); c->d_maskws.release(); c->d_prof.release();
+    c->d_counts.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_small.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
     if (c->staged) (void)hipEventDestroy(c->staged);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -501,6 +501,19 @@ int32_t cramgpu_assign_codes_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t*
     if (rc) return rc;
     HIPCHK(launch_assign_codes(n_reads, d_read_cont, feats->off, feats->op, feats->a, c->d_small.p, s));
     HIPCHK(hipStreamSynchronize(s));  // d_small is reused by the next call
+    return 0;
+}
+
+int32_t cramgpu_matrices_assign_codes_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_cont, int32_t n_cont,
+                                          const cramgpu_features* feats, const int64_t* d_sub_hist, uint8_t* d_matrices,
+                                          void* stream) {
+    if (!c || !feats || !d_sub_hist || !d_matrices || n_reads < 0 || n_cont < 1)
+        return fail(CRAMGPU_E_ARG, "matrices_assign_codes: bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(c->d_codes25.reserve((size_t)n_cont * 25));
+    HIPCHK(launch_matrices_and_codes(d_sub_hist, n_cont, d_matrices, c->d_codes25.p, n_reads, d_read_cont, feats->off, feats->op,
+                                     feats->a, pick(c, stream)));
     return 0;
 }
 

@@ -63,6 +63,8 @@ hipError_t launch_feature_scan(int32_t n_reads, const int32_t* d_counts, int64_t
                                hipStream_t s);
 hipError_t launch_assign_codes(int32_t n_reads, const int32_t* read_cont, const int64_t* off, const uint8_t* op,
                                int32_t* a, const uint8_t* d_codes, hipStream_t s);
+hipError_t launch_matrices_and_codes(const int64_t* d_hist, int32_t n_cont, uint8_t* d_mat5, uint8_t* d_codes25, int32_t n_reads,
+                                     const int32_t* read_cont, const int64_t* off, const uint8_t* op, int32_t* a, hipStream_t s);
 hipError_t launch_restore_bases(int32_t n_reads, const int32_t* read_len, const int32_t* aln_start, const uint8_t* rflags,
                                 const int32_t* read_cont, const cramgpu_refwin* wins, cramgpu_features f,
                                 const uint8_t* seq, const int64_t* seq_off, const uint8_t* ref, const uint8_t* d_basesof,

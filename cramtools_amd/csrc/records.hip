@@ -42,95 +42,152 @@ __device__ __forceinline__ int wave_count() { return (int)((gridDim.x * blockDim
 
 // ------------------------------------------------------------------------------------------------------
 // K3: feature extraction.  WRITE=false: counts[r] = number of features of read r.  WRITE=true: emit at off[r].
+// A wave takes tiles of 64 consecutive reads: every lane loads the metadata of one read of the tile (coalesced, one
+// memory round trip for the tile), the reads are then walked one by one with their metadata broadcast from the
+// owning lane, and a match run is swept 256 bases at a time with all its loads issued before the first use.
 // ------------------------------------------------------------------------------------------------------
+#ifdef HIP_SIM
+template <class T>
+__device__ __forceinline__ T lane_bcast(T v, int k) { return __shfl(v, k); }
+#else
+__device__ __forceinline__ int32_t lane_bcast(int32_t v, int k) { return __builtin_amdgcn_readlane(v, k); }
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, k); }
+__device__ __forceinline__ int64_t lane_bcast(int64_t v, int k) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, k);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), k);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+#endif
+
 template <bool WRITE>
 __global__ __launch_bounds__(256) void extract_kernel(cramgpu_reads R, const uint8_t* ref, cramgpu_features F,
                                                       int64_t* sub_hist, int32_t* counts) {
     const int lane = threadIdx.x & 63;
     const int n_waves = wave_count();
-    for (int r = wave_index(); r < R.n_reads; r += n_waves) {
-        const uint8_t fl = R.rflags[r];
-        const int32_t start = R.aln_start[r];
-        const int cont = R.read_cont ? R.read_cont[r] : 0;
-        int64_t nf = 0;
-        const int64_t o = WRITE ? F.off[r] : 0;
-        if (!(fl & (CRAMGPU_RF_UNMAPPED | CRAMGPU_RF_SKIP)) && start != 0) {
-            const cramgpu_refwin W = R.win[cont];
-            const uint8_t* wref = ref + W.ref_off;
-            const uint8_t* rb = R.bases + R.base_off[r];
-            const bool nobases = (fl & CRAMGPU_RF_NO_BASES) != 0;
-            const int nc = R.n_cigar[r];
-            const uint32_t* cg = R.cigar + R.cigar_off[r];
-            int pos = 0, refoff = 0;
-            for (int k = 0; k < nc; k++) {
-                const uint32_t ce = cg[k];
-                const int op = (int)(ce & 15u), len = (int)(ce >> 4);
-                if (op == OP_D || op == OP_N || op == OP_P || op == OP_H || op == OP_S) {
-                    if (WRITE && lane == 0) {
-                        const int64_t i = o + nf;
-                        F.op[i] = op == OP_D ? 'D' : op == OP_N ? 'N' : op == OP_P ? 'P' : op == OP_H ? 'H' : 'S';
-                        F.pos[i] = pos + 1;
-                        F.a[i] = op == OP_S ? pos : len;
-                        F.b[i] = op == OP_S ? len : 0;
-                    }
-                    nf += 1;
-                } else if (op == OP_I) {
-                    if (WRITE) {
-                        for (int i = lane; i < len; i += 64) {
-                            const int64_t x = o + nf + i;
-                            F.op[x] = 'i';
-                            F.pos[x] = pos + 1 + i;
-                            F.a[x] = nobases ? 'N' : rb[pos + i];
-                            F.b[x] = 0;
+    const int n_tiles = (R.n_reads + 63) >> 6;
+    for (int tile = wave_index(); tile < n_tiles; tile += n_waves) {
+        const int r0 = tile << 6;
+        const int rm = r0 + lane;
+        const bool valid = rm < R.n_reads;
+        // one read's metadata per lane
+        int32_t m_fl = CRAMGPU_RF_SKIP, m_start = 0, m_nc = 0, m_cont = 0;
+        int64_t m_boff = 0, m_coff = 0, m_off = 0;
+        uint32_t m_ce0 = 0;
+        if (valid) {
+            m_fl = R.rflags[rm];
+            m_start = R.aln_start[rm];
+            m_nc = R.n_cigar[rm];
+            m_boff = R.base_off[rm];
+            m_coff = R.cigar_off[rm];
+            if (R.read_cont) m_cont = R.read_cont[rm];
+            if (WRITE) m_off = F.off[rm];
+            if (m_nc > 0) m_ce0 = R.cigar[m_coff];
+        }
+        int32_t nf_mine = 0;
+        const int in_tile = min(64, R.n_reads - r0);
+        cramgpu_refwin W{0, 0, 0};
+        int wcont = -1;
+        for (int k = 0; k < in_tile; k++) {
+            const int32_t fl = lane_bcast(m_fl, k);
+            const int32_t start = lane_bcast(m_start, k);
+            const bool mapped = !(fl & (CRAMGPU_RF_UNMAPPED | CRAMGPU_RF_SKIP)) && start != 0;
+            const int cont = lane_bcast(m_cont, k);
+            if (mapped && cont != wcont) {
+                W = R.win[cont];
+                wcont = cont;
+            }
+            int64_t nf = 0;
+            if (mapped) {
+                const int nc = lane_bcast(m_nc, k);
+                const int64_t o = WRITE ? lane_bcast(m_off, k) : 0;
+                const uint8_t* wref = ref + W.ref_off;
+                const uint8_t* rb = R.bases + lane_bcast(m_boff, k);
+                const bool nobases = (fl & CRAMGPU_RF_NO_BASES) != 0;
+                const uint32_t* cg = R.cigar + lane_bcast(m_coff, k);
+                const uint32_t ce0 = lane_bcast(m_ce0, k);
+                int pos = 0, refoff = 0;
+                for (int e = 0; e < nc; e++) {
+                    const uint32_t ce = e == 0 ? ce0 : cg[e];
+                    const int op = (int)(ce & 15u), len = (int)(ce >> 4);
+                    if (op == OP_D || op == OP_N || op == OP_P || op == OP_H || op == OP_S) {
+                        if (WRITE && lane == 0) {
+                            const int64_t i = o + nf;
+                            F.op[i] = op == OP_D ? 'D' : op == OP_N ? 'N' : op == OP_P ? 'P' : op == OP_H ? 'H' : 'S';
+                            F.pos[i] = pos + 1;
+                            F.a[i] = op == OP_S ? pos : len;
+                            F.b[i] = op == OP_S ? len : 0;
                         }
-                    }
-                    nf += len;
-                } else if (op == OP_M || op == OP_EQ || op == OP_X) {
-                    for (int i0 = 0; i0 < len; i0 += 64) {
-                        const int i = i0 + lane;
-                        bool mis = false;
-                        uint8_t b = 0, refb = 0;
-                        if (i < len) {
-                            const int64_t rc = (int64_t)start + i + refoff - 1 - W.ref_start0;
-                            refb = (rc < 0 || rc >= W.ref_len) ? (uint8_t)'N' : wref[rc];
-                            refb = normalize_base(refb);
-                            b = nobases ? (uint8_t)'N' : rb[pos + i];
-                            mis = b != refb;
-                        }
-                        const unsigned long long m = __ballot(mis);
-                        if (WRITE && m) {
-                            int key = -1;
-                            if (mis) {
-                                const int64_t x = o + nf + mbcnt(m);
-                                F.op[x] = 'X';
-                                F.pos[x] = pos + i + 1;
-                                F.a[x] = (int32_t)b | ((int32_t)refb << 8) | (0xFF << 16);
+                        nf += 1;
+                    } else if (op == OP_I) {
+                        if (WRITE) {
+                            for (int i = lane; i < len; i += 64) {
+                                const int64_t x = o + nf + i;
+                                F.op[x] = 'i';
+                                F.pos[x] = pos + 1 + i;
+                                F.a[x] = nobases ? 'N' : rb[pos + i];
                                 F.b[x] = 0;
-                                const int bi = acgtn_index(b);
-                                if (bi >= 0) key = acgtn_index(refb) * 5 + bi;
                             }
-                            if (sub_hist) {
-                                // one atomic per distinct (ref, base) pair of the wave
-                                unsigned long long todo = __ballot(key >= 0);
-                                while (todo) {
-                                    const int leader = __ffsll((long long)todo) - 1;
-                                    const int k0 = __shfl(key, leader);
-                                    const unsigned long long same = __ballot(key == k0);
-                                    if (lane == leader)
-                                        atomicAdd((unsigned long long*)&sub_hist[(int64_t)cont * 25 + k0],
-                                                  (unsigned long long)__popcll(same));
-                                    todo &= ~same;
+                        }
+                        nf += len;
+                    } else if (op == OP_M || op == OP_EQ || op == OP_X) {
+                        const int64_t rc0 = (int64_t)start + refoff - 1 - W.ref_start0;  // window index of the run's base 0
+                        for (int i0 = 0; i0 < len; i0 += 256) {
+                            uint8_t bb[4], rr[4];
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {  // all loads of the sweep before the first use
+                                const int i = i0 + 64 * c + lane;
+                                bb[c] = 'N';
+                                rr[c] = 'N';
+                                if (i < len) {
+                                    const int64_t rc = rc0 + i;
+                                    if (rc >= 0 && rc < W.ref_len) rr[c] = wref[rc];
+                                    if (!nobases) bb[c] = rb[pos + i];
                                 }
                             }
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                const int i = i0 + 64 * c + lane;
+                                if (i0 + 64 * c >= len) break;
+                                const uint8_t refb = normalize_base(rr[c]);
+                                const uint8_t b = bb[c];
+                                const bool mis = i < len && b != refb;
+                                const unsigned long long m = __ballot(mis);
+                                if (WRITE && m) {
+                                    int key = -1;
+                                    if (mis) {
+                                        const int64_t x = o + nf + mbcnt(m);
+                                        F.op[x] = 'X';
+                                        F.pos[x] = pos + i + 1;
+                                        F.a[x] = (int32_t)b | ((int32_t)refb << 8) | (0xFF << 16);
+                                        F.b[x] = 0;
+                                        const int bi = acgtn_index(b);
+                                        if (bi >= 0) key = acgtn_index(refb) * 5 + bi;
+                                    }
+                                    if (sub_hist) {
+                                        // one atomic per distinct (ref, base) pair of the wave
+                                        unsigned long long todo = __ballot(key >= 0);
+                                        while (todo) {
+                                            const int leader = __ffsll((long long)todo) - 1;
+                                            const int k0 = __shfl(key, leader);
+                                            const unsigned long long same = __ballot(key == k0);
+                                            if (lane == leader)
+                                                atomicAdd((unsigned long long*)&sub_hist[(int64_t)cont * 25 + k0],
+                                                          (unsigned long long)__popcll(same));
+                                            todo &= ~same;
+                                        }
+                                    }
+                                }
+                                nf += __popcll(m);
+                            }
                         }
-                        nf += __popcll(m);
                     }
+                    if (consumes_read(op)) pos += len;
+                    if (consumes_ref(op)) refoff += len;
                 }
-                if (consumes_read(op)) pos += len;
-                if (consumes_ref(op)) refoff += len;
             }
+            if (lane == k) nf_mine = (int32_t)nf;
         }
-        if (!WRITE && lane == 0) counts[r] = (int32_t)nf;
+        if (!WRITE && valid) counts[rm] = nf_mine;
     }
 }
 
@@ -224,6 +281,47 @@ __global__ void assign_codes_kernel(int32_t n_reads, const int32_t* read_cont, c
         const int32_t v = a[f];
         const int ri = acgtn_index((uint8_t)(v >> 8));
         const int code = ri >= 0 ? cd[ri * 256 + (v & 0xff)] : 0;
+        a[f] = (v & 0xffff) | (code << 16);
+    }
+}
+
+// F3 on the device: SubstitutionMatrix#<init>([[J) L38-57 / #rank L141-169 for every container of a batch, a thread
+// per container.  mat5 = the 5 header bytes, codes25[cont][ref 5][base 5] = SubstitutionMatrix#code over ACGTN.
+__global__ void matrices_kernel(const int64_t* hist, int32_t n_cont, uint8_t* mat5, uint8_t* codes25) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cont) return;
+    const int64_t* h = hist + (int64_t)c * 25;
+    for (int r = 0; r < 5; r++) {
+        int others[4], k = 0;
+        for (int b = 0; b < 5; b++)
+            if (b != r) others[k++] = b;
+        // rank = number of bases that sort before: larger count, or equal count and earlier in ACGTN order (stable)
+        uint32_t byte = 0;
+        for (int i = 0; i < 4; i++) {
+            int rank = 0;
+            for (int j2 = 0; j2 < 4; j2++) {
+                const int64_t a = h[r * 5 + others[j2]], b2 = h[r * 5 + others[i]];
+                if (a > b2 || (a == b2 && j2 < i)) rank++;
+            }
+            byte |= (uint32_t)rank << (6 - 2 * i);
+            codes25[(int64_t)c * 25 + r * 5 + others[i]] = (uint8_t)rank;
+        }
+        codes25[(int64_t)c * 25 + r * 5 + r] = 0;
+        mat5[(int64_t)c * 5 + r] = (uint8_t)byte;
+    }
+}
+
+// Writer#write L139-261 -> SubstitutionMatrix#code with the device tables of matrices_kernel
+__global__ void assign_codes25_kernel(int32_t n_reads, const int32_t* read_cont, const int64_t* off, const uint8_t* op,
+                                      int32_t* a, const uint8_t* codes25) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint8_t* cd = codes25 + (size_t)(read_cont ? read_cont[r] : 0) * 25;
+    for (int64_t f = off[r]; f < off[r + 1]; f++) {
+        if (op[f] != 'X') continue;
+        const int32_t v = a[f];
+        const int ri = acgtn_index((uint8_t)(v >> 8)), bi = acgtn_index((uint8_t)v);
+        const int code = (ri >= 0 && bi >= 0) ? cd[ri * 5 + bi] : 0;
         a[f] = (v & 0xffff) | (code << 16);
     }
 }
@@ -631,7 +729,7 @@ static int grid_for_waves(int64_t n_items, int waves_per_block) {
 
 hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
                                    int32_t* d_counts, bool write_pass, hipStream_t s) {
-    const int grid = grid_for_waves(r.n_reads, 4);
+    const int grid = grid_for_waves(((int64_t)r.n_reads + 63) / 64, 4);  // a wave per tile of 64 reads
     if (write_pass)
         hipLaunchKernelGGL(extract_kernel<true>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts);
     else
@@ -658,6 +756,15 @@ hipError_t launch_assign_codes(int32_t n_reads, const int32_t* read_cont, const 
                                int32_t* a, const uint8_t* d_codes, hipStream_t s) {
     hipLaunchKernelGGL(assign_codes_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, s, n_reads, read_cont, off, op, a,
                        d_codes);
+    return hipGetLastError();
+}
+
+hipError_t launch_matrices_and_codes(const int64_t* d_hist, int32_t n_cont, uint8_t* d_mat5, uint8_t* d_codes25, int32_t n_reads,
+                                     const int32_t* read_cont, const int64_t* off, const uint8_t* op, int32_t* a, hipStream_t s) {
+    hipLaunchKernelGGL(matrices_kernel, dim3((n_cont + 63) / 64), dim3(64), 0, s, d_hist, n_cont, d_mat5, d_codes25);
+    if (n_reads > 0)
+        hipLaunchKernelGGL(assign_codes25_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, s, n_reads, read_cont, off, op, a,
+                           d_codes25);
     return hipGetLastError();
 }
 

@@ -193,6 +193,15 @@ class Sam2CramRecordFactory:
             reads.n_cont, C.byref(fs), m.ctypes.data, _stream()))
 
 
+    def matrices_and_codes(self, reads, feats, d_hist, d_matrices):
+        """F3 + code assignment on the device (no host round trip): d_hist int64[n_cont*25] from create_variations,
+        d_matrices uint8[n_cont*5] receives the SubstitutionMatrix header bytes of every container."""
+        fs = feats.struct()
+        _lib.check(_lib.lib().cramgpu_matrices_assign_codes_dev(
+            self.engine.handle, reads.n, reads.read_cont.data_ptr() if reads.read_cont is not None else None,
+            reads.n_cont, C.byref(fs), d_hist.data_ptr(), d_matrices.data_ptr(), _stream()))
+
+
 class CramNormalizer:
     """src/main/java/htsjdk/samtools/cram/build/CramNormalizer.java: base and quality restoration (decode side)."""
 

@@ -198,6 +198,15 @@ void cramgpu_substitution_matrix(const int64_t* sub_hist, uint8_t* matrix5);
 int32_t cramgpu_assign_codes_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32_t* d_read_cont, int32_t n_cont,
                                  const cramgpu_features* feats, const uint8_t* matrices, void* stream);
 
+/* F3 + code assignment without a host round trip: htsjdk!structure/SubstitutionMatrix#<init>([[J) (L38-57) for every
+ * container of the batch from d_sub_hist[n_cont][25] (as accumulated by cramgpu_extract_features_dev), the 5 header
+ * bytes of container k written to d_matrices[5k..5k+5) (DEVICE), then Writer#write's matrix.code(ref, base) for every
+ * X feature as in cramgpu_assign_codes_dev.  Stream-ordered, does not synchronise; the context keeps the code tables
+ * until its next call of this function. */
+int32_t cramgpu_matrices_assign_codes_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32_t* d_read_cont, int32_t n_cont,
+                                          const cramgpu_features* feats, const int64_t* d_sub_hist, uint8_t* d_matrices,
+                                          void* stream);
+
 /* K4 / N1 — src/main/java/htsjdk/samtools/cram/build/CramNormalizer.java:335-441 (restoreReadBases), called from
  * :137 and :239 with a ReferenceRegion window (d_wins[n_cont] into d_ref).  matrices = HOST n_cont x 5 bytes.
  * d_seq/d_seq_off: bytes of S / I features (feature a = offset relative to d_seq_off[r]).

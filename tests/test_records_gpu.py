@@ -236,3 +236,69 @@ def test_multi_container_batch(rk, orc):
         fbase += k
         base += o_reads.n
     assert fbase == feats.count
+
+
+def test_device_matrices_match_host_path(rk, orc):
+    """cramgpu_matrices_assign_codes_dev (F3 on the device) gives the matrices and codes of the host path."""
+    records, eng = rk
+    import torch
+    rng = np.random.default_rng(21)
+    parts = [_random_container(rng, 60, 3000), _random_container(rng, 70, 2500), _random_container(rng, 5, 500)]
+    refs = [p[0] for p in parts]
+    arena, wins, o = [], [], 0
+    for r in refs:
+        arena += [r, np.zeros(16, np.uint8)]
+        wins.append((o, len(r), 0))
+        o += len(r) + 16
+    st = np.concatenate([p[1] for p in parts])
+    cigars = sum((p[2] for p in parts), [])
+    bases = sum((p[3] for p in parts), [])
+    rflags = np.concatenate([p[5] for p in parts])
+    cont = np.concatenate([np.full(len(p[1]), c, np.int32) for c, p in enumerate(parts)])
+    reads = records.ReadBatch.from_lists(DEV, st, cigars, bases, rflags=rflags)
+    reads.read_cont = torch.as_tensor(cont).to(DEV)
+    reads.n_cont = len(parts)
+    reads.win = torch.as_tensor(np.asarray(wins, np.int64).reshape(-1)).to(DEV)
+    fac = records.Sam2CramRecordFactory(eng)
+    fac.set_ref_bases(torch.as_tensor(np.concatenate(arena)).to(DEV))
+    feats, hist = fac.create_variations(reads)
+    mats = np.stack([records.substitution_matrix(hist[c]) for c in range(len(parts))])
+    for c in range(len(parts)):
+        assert np.array_equal(mats[c], orc.substitution_matrix(hist[c]))
+    a_before = feats.a.clone()
+    fac.assign_codes(reads, feats, mats)
+    want_a = feats.a.clone()
+    feats.a.copy_(a_before)
+    d_hist = torch.as_tensor(hist.reshape(-1)).to(DEV)
+    d_mats = torch.zeros(len(parts) * 5, dtype=torch.uint8, device=DEV)
+    fac.matrices_and_codes(reads, feats, d_hist, d_mats)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_mats.cpu().numpy().reshape(-1, 5), mats)
+    assert torch.equal(feats.a[:feats.count], want_a[:feats.count])
+
+
+def test_many_reads_offsets(rk, orc):
+    """More reads than one scan tile (4096): feature offsets and features still equal the oracle's."""
+    records, eng = rk
+    rng = np.random.default_rng(33)
+    n, ref_len = 9500, 40000
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), ref_len)
+    starts = np.sort(rng.integers(1, ref_len - 60, n))
+    cigars, bases = [], []
+    for r in range(n):
+        L = int(rng.integers(20, 50))
+        b = ref[starts[r] - 1:starts[r] - 1 + L].copy()
+        flip = rng.random(L) < 0.08
+        b[flip] = rng.choice(np.frombuffer(b"ACGTN", np.uint8), int(flip.sum()))
+        cigars.append([(L << 4) | 0])
+        bases.append(b.tobytes())
+    o_reads = orc.Reads(starts, cigars, bases)
+    reads = records.ReadBatch.from_lists(DEV, starts, cigars, bases, ref_len=len(ref))
+    fac = records.Sam2CramRecordFactory(eng)
+    fac.set_ref_bases(_dref(ref.tobytes()))
+    feats, hist = fac.create_variations(reads)
+    want = orc.extract_features(o_reads, ref)
+    got = feats.to_host()
+    for key in ("off", "op", "pos", "a"):
+        assert np.array_equal(got[key], want[key]), key
+    assert np.array_equal(hist[0], want["hist"])
