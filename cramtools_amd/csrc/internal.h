@@ -25,9 +25,9 @@
 #define RANS_BYTE_L (1u << 23)
 
 // global scratch of one resident rANS workgroup: order-1 tables that do not fit LDS
-//   encode: counts u32[256][256] (256 KiB) + packed symbols uint2[256][256] (512 KiB)
+//   encode: counts u32[n][n|1] (<= 257 KiB, at 0) + packed symbols uint2[n][n|1] (<= 514 KiB, at 264 KiB), n <= 256
 //   decode: order-1 rows u32[256][256] (256 KiB)
-#define ENC_GSCRATCH_BYTES (768u * 1024u)
+#define ENC_GSCRATCH_BYTES (784u * 1024u)
 #define DEC_GSCRATCH_BYTES (256u * 1024u)
 
 struct RansArgs {

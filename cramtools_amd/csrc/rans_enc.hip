@@ -25,7 +25,7 @@
 //                      and logs the pre-renormalisation states of a batch with four 16-byte LDS writes.
 // The two waves meet at one workgroup barrier per batch; staging and log are double buffered.
 // Order-1 tables live in LDS over the compacted alphabet (present symbols + 0) when n*(n|1)*12 B fits the table
-// region, else in a per-workgroup global scratch over the full 256x256 alphabet.
+// region, else (same dense layout) in a per-workgroup global scratch.
 #include <climits>
 
 #include "internal.h"
@@ -239,18 +239,14 @@ __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n,
     WSYNC();
     const int32_t n16 = n & ~15;
     for_each_unit<true>(src, n16, l, [&](const uint4& v, int32_t, uint32_t prev) {
-        uint32_t row = (uint32_t)dmap[prev] * (uint32_t)stride;
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        // all 17 index look-ups first: interleaved with the atomics every look-up would wait out an LDS round trip
+        uint32_t col[17];
+        col[0] = dmap[prev];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 16; k++) col[k + 1] = dmap[(w[k >> 2] >> (8 * (k & 3))) & 255u];
 #pragma unroll
-            for (int bshift = 0; bshift < 32; bshift += 8) {
-                uint32_t c = (w[k] >> bshift) & 255u;
-                uint32_t col = (uint32_t)dmap[c];
-                atomicAdd(&my[row + col], 1u);
-                row = col * (uint32_t)stride;
-            }
-        }
+        for (int k = 0; k < 16; k++) atomicAdd(&my[col[k] * (uint32_t)stride + col[k + 1]], 1u);
     });
     if (n16 + l < n) {
         int32_t i = n16 + l;
@@ -274,6 +270,41 @@ __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n,
         }
         WSYNC();
     }
+}
+
+// Order-1 pair counts of a SHORT block (n < 65536) over an alphabet too wide for 32-bit LDS counters: two 16-bit
+// counters per LDS word.  Global-memory atomics on the few hot cells of such a stream (one L2 round trip each, all
+// lanes on the same address) cost ~100 cycles per byte; LDS atomics a few.  The counts are then unpacked into the
+// global table cnt[cells].
+__device__ __attribute__((noinline)) void hist_o1_packed16(const uint8_t* src, int32_t n, uint32_t* cnt, int stride, const uint8_t* dmap,
+                                                           uint32_t* w, int cells) {
+    const int l = lane_id();
+    const int words = (cells + 1) >> 1;
+    for (int i = l; i < words; i += 64) w[i] = 0;
+    WSYNC();
+    auto bump = [&](uint32_t idx) { atomicAdd(&w[idx >> 1], 1u << (16u * (idx & 1u))); };
+    const int32_t n16 = n & ~15;
+    for_each_unit<true>(src, n16, l, [&](const uint4& v, int32_t, uint32_t prev) {
+        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+        uint32_t col[17];
+        col[0] = dmap[prev];
+#pragma unroll
+        for (int k = 0; k < 16; k++) col[k + 1] = dmap[(x[k >> 2] >> (8 * (k & 3))) & 255u];
+#pragma unroll
+        for (int k = 0; k < 16; k++) bump(col[k] * (uint32_t)stride + col[k + 1]);
+    });
+    if (n16 + l < n) {
+        const int32_t i = n16 + l;
+        const uint32_t prev = i ? src[i - 1] : 0u, c = src[i];
+        bump((uint32_t)dmap[prev] * (uint32_t)stride + dmap[c]);
+    }
+    if (l == 0) {  // L170-173: the three quarter-start symbols are also counted in context 0
+        const int32_t q = n >> 2;
+        for (int k = 1; k < 4; k++) bump((uint32_t)dmap[src[k * q]]);
+    }
+    WSYNC();
+    for (int i = l; i < cells; i += 64) cnt[i] = (w[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+    WSYNC();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -419,6 +450,126 @@ __device__ __attribute__((noinline)) int32_t tables_o1(uint32_t* cnt, uint2* ent
     return (int32_t)total + 1;
 }
 
+// tables_o1 for counts that live in GLOBAL memory (alphabets too wide for the LDS table region).  Walking a row of
+// global memory element by element costs a memory round trip per element, so the rows are staged through the LDS
+// table region G at a time (coalesced copies), one row per lane, in two sweeps: normalise + measure, then (after the
+// scan of the row lengths) serialise + build the symbols.  Same arithmetic, same row_body, as tables_o1.
+__device__ __attribute__((noinline)) int32_t tables_o1_staged(uint32_t* cnt, uint2* ent, int n, int stride, EncFixedLds* L,
+                                                              uint32_t* stg, int G, uint8_t* tabdst, const uint32_t* rcp_tab,
+                                                              int32_t tab_cap) {
+    const int l = lane_id();
+    // sweep 1: normalise (L175-193), body length of every row
+#pragma unroll 1
+    for (int g0 = 0; g0 < n; g0 += G) {
+        const int rows = min(G, n - g0), words = rows * stride;
+        for (int i = l; i < words; i += 64) stg[i] = cnt[g0 * stride + i];
+        WSYNC();
+        if (l < rows) {
+            const int row = g0 + l;
+            uint32_t* c = stg + l * stride;
+            uint32_t T = 0;
+            for (int j = 0; j < n; j++) T += c[j];
+            L->p2.rowT[row] = T;
+            uint32_t blen = 0;
+            if (T != 0) {
+                const double p = 4096.0 / (double)(int32_t)T;
+                int32_t m = 0, M = 0, t2 = 0;
+                for (int j = 0; j < n; j++) {
+                    int32_t v = (int32_t)c[j];
+                    if (v == 0) continue;
+                    if (m < v) {
+                        m = v;
+                        M = j;
+                    }
+                    int32_t f = (int32_t)((double)v * p);
+                    if (f == 0) f = 1;
+                    t2 += f;
+                    c[j] = (uint32_t)f;
+                }
+                t2++;
+                c[M] = (uint32_t)((int32_t)c[M] + (RANS_TOTFREQ - t2));
+                blen = (uint32_t)row_body<false>(c, n, L->syml, nullptr);
+            }
+            L->p2.rowoff[row] = blen;
+        }
+        WSYNC();
+        for (int i = l; i < words; i += 64) cnt[g0 * stride + i] = stg[i];
+        WSYNC();
+    }
+    __threadfence();
+    WSYNC();
+    // context headers (writeFrequencies_o1 L269-328) and offsets: 4 consecutive rows per lane, n <= 256
+    uint32_t len4[4], mylen = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int row = l * 4 + k;
+        uint32_t len = 0, hdr = 0;
+        if (row < n && L->p2.rowT[row] != 0) {
+            const int v = L->syml[row];
+            const bool link = v > 0 && row > 0 && L->syml[row - 1] == v - 1 && L->p2.rowT[row - 1] != 0;
+            if (!link) {
+                hdr = 1u | ((uint32_t)v << 8);
+            } else {
+                const int pv = v - 1;
+                const bool plink = pv > 0 && row > 1 && L->syml[row - 2] == pv - 1 && L->p2.rowT[row - 2] != 0;
+                if (!plink) {
+                    int kk = row + 1;
+                    while (kk < n && L->syml[kk] == L->syml[kk - 1] + 1 && L->p2.rowT[kk] != 0) kk++;
+                    hdr = 2u | ((uint32_t)v << 8) | ((uint32_t)(kk - (row + 1)) << 16);
+                }
+            }
+            len = (hdr & 3u) + L->p2.rowoff[row];
+        }
+        len4[k] = len;
+        if (row < n) L->p2.rowhdr[row] = hdr;
+        mylen += len;
+    }
+    uint32_t total;
+    uint32_t base = wave_excl_scan(mylen, total);
+    WSYNC();
+    if (total > 257u * 257u * 3u || (int64_t)total + 1 > (int64_t)tab_cap) return CRAMGPU_E_INSUFFICIENT;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int row = l * 4 + k;
+        if (row < n) L->p2.rowoff[row] = base | (len4[k] << 20);  // offset < 2^18, length < 2^10
+        base += len4[k];
+    }
+    WSYNC();
+    // sweep 2: serialise and build the encoder symbols (buildSyms_o1 L248-265)
+#pragma unroll 1
+    for (int g0 = 0; g0 < n; g0 += G) {
+        const int rows = min(G, n - g0), words = rows * stride;
+        for (int i = l; i < words; i += 64) stg[i] = cnt[g0 * stride + i];
+        WSYNC();
+        if (l < rows) {
+            const int row = g0 + l;
+            const uint32_t* c = stg + l * stride;
+            const uint32_t ol = L->p2.rowoff[row], off = ol & 0xFFFFFu, len = ol >> 20;
+            if (len != 0 && off + len <= total) {
+                const uint32_t hdr = L->p2.rowhdr[row];
+                uint8_t* d = tabdst + off;
+                if ((hdr & 3u) >= 1) d[0] = (uint8_t)(hdr >> 8);
+                if ((hdr & 3u) == 2) d[1] = (uint8_t)(hdr >> 16);
+                row_body<true>(c, n, L->syml, d + (hdr & 3u));
+            }
+            if (L->p2.rowT[row] != 0) {
+                uint2* e = ent + row * stride;
+                uint32_t C = 0;
+                for (int j = 0; j < n; j++) {
+                    int32_t f = (int32_t)c[j];
+                    if (f == 0) continue;
+                    e[j] = pack_symbol(f, C, rcp_tab);
+                    C += (uint32_t)f;
+                }
+            }
+        }
+        WSYNC();
+    }
+    if (l == 0) tabdst[total] = 0;
+    WSYNC();
+    return (int32_t)total + 1;
+}
+
 // order-0: Frequencies#calcFrequencies_o0 L109-145, #writeFrequencies_o0 L215-244, #buildSyms_o0 L197-211.
 // cnt[256] raw counts in, normalised out; ent[256].
 __device__ int32_t tables_o0(uint32_t* cnt, uint2* ent, int32_t n_in, EncFixedLds* L, uint8_t* tabdst,
@@ -481,6 +632,8 @@ __device__ int32_t tables_o0(uint32_t* cnt, uint2* ent, int32_t n_in, EncFixedLd
 // phase 3: the coding loop (both waves)
 // ---------------------------------------------------------------------------------------------------------
 enum { MODE_O0 = 0, MODE_O1_LDS = 1, MODE_O1_GLOBAL = 2 };
+constexpr int kGsEntOff = 264 * 1024;  // global scratch: packed symbols behind 256 x 257 counts
+static_assert(kGsEntOff >= 4 * 256 * 257 && kGsEntOff + 8 * 256 * 257 <= (int)ENC_GSCRATCH_BYTES, "global scratch layout");
 
 // Barrier between the two waves of the workgroup.  Only LDS traffic is exchanged across it, so it waits for the LDS
 // counter alone: __syncthreads() would also drain the helper wave's global loads and stores (a full memory round
@@ -513,7 +666,7 @@ __device__ __forceinline__ bool active_of(const Geo& g, int32_t u, int j, int32_
     if (MODE == MODE_O0) return pos < g.n;
     return j == 3 || u >= g.rem;
 }
-// ring address of input position pos of state j: the ring holds dense symbol indices (order 1, LDS tables) or bytes
+// ring address of input position pos of state j: the ring holds dense symbol indices (order 1) or bytes (order 0)
 template <int MODE>
 __device__ __forceinline__ int ring_addr(int32_t pos, int j) {
     if (MODE == MODE_O0) return pos & (kRingBytes - 1);
@@ -572,7 +725,7 @@ __device__ __forceinline__ void chunk_store(const ChunkRegs& R, uint8_t* ring, c
     for (int k = 0; k < 2; k++) {
         if (R.pos[k] >= 0) {
             uint4 v = R.v[k];
-            if (MODE == MODE_O1_LDS) v = make_uint4(dense4(v.x, dmap), dense4(v.y, dmap), dense4(v.z, dmap), dense4(v.w, dmap));
+            if (MODE != MODE_O0) v = make_uint4(dense4(v.x, dmap), dense4(v.y, dmap), dense4(v.z, dmap), dense4(v.w, dmap));
             *reinterpret_cast<uint4*>(ring + R.ring[k]) = v;
         }
     }
@@ -889,9 +1042,9 @@ __device__ __attribute__((noinline)) int32_t stream_o1_lds(Blk B, int32_t tab_le
     const uint2* ent = reinterpret_cast<const uint2*>(lds.tab + ent_off);
     return encode_stream<MODE_O1_LDS>(B.src, B.n, ent, stride, B.slot + B.cap, B.cap - 9 - tab_len, B.prof);
 }
-__device__ __attribute__((noinline)) int32_t stream_o1_global(Blk B, int32_t tab_len) {
-    const uint2* ent = reinterpret_cast<const uint2*>(B.gs + 256 * 1024);
-    return encode_stream<MODE_O1_GLOBAL>(B.src, B.n, ent, 256, B.slot + B.cap, B.cap - 9 - tab_len, B.prof);
+__device__ __attribute__((noinline)) int32_t stream_o1_global(Blk B, int32_t tab_len, int32_t stride) {
+    const uint2* ent = reinterpret_cast<const uint2*>(B.gs + kGsEntOff);
+    return encode_stream<MODE_O1_GLOBAL>(B.src, B.n, ent, stride, B.slot + B.cap, B.cap - 9 - tab_len, B.prof);
 }
 
 // ---- phases 1 and 2, helper wave only ----
@@ -911,35 +1064,9 @@ __device__ __attribute__((noinline)) Prep prep_o0(Blk B) {
     return r;
 }
 
-__device__ __attribute__((noinline)) Prep prep_o1_global(Blk B) {
-    const int l = lane_id();
-    EncFixedLds* L = &lds;
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(B.gs);
-    uint2* ent = reinterpret_cast<uint2*>(B.gs + 256 * 1024);
-    uint4* z = reinterpret_cast<uint4*>(B.gs);
-    for (int i = l; i < 256 * 1024 / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
-    for (int i = l; i < 256; i += 64) {
-        L->syml[i] = (uint8_t)i;
-        L->dmap[i] = (uint8_t)i;
-    }
-    __threadfence();
-    WSYNC();
-    hist_o1(B.src, B.n, cnt, 256, L->dmap, nullptr, 1, 0, 0);
-    __threadfence();
-    WSYNC();
-    Prep r{MODE_O1_GLOBAL, 256, 0, 0, 0};
-    r.tab_len = tables_o1(cnt, ent, 256, 256, 256, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
-    __threadfence();
-    WSYNC();
-    if (r.tab_len < 0)
-        r.status = r.tab_len;
-    else if (9 + r.tab_len + 16 > B.cap)
-        r.status = CRAMGPU_E_INSUFFICIENT;
-    return r;
-}
-
-// status == INT32_MIN when the alphabet does not fit the LDS table region
-__device__ __attribute__((noinline)) Prep prep_o1_lds(Blk B) {
+// Order 1: counts and packed symbols over the dense alphabet, in the LDS table region when 12 bytes per cell fit, else
+// in the workgroup's global scratch (same layout, same code: hist_o1 / tables_o1 take generic pointers).
+__device__ __attribute__((noinline)) Prep prep_o1(Blk B) {
     const int l = lane_id();
     EncFixedLds* L = &lds;
     uint8_t* tab = lds.tab;
@@ -973,21 +1100,45 @@ __device__ __attribute__((noinline)) Prep prep_o1_lds(Blk B) {
     const int ns = (int)nsym;
     const int stride = ns | 1;
     const int cells = ns * stride;
-    Prep r{MODE_O1_LDS, stride, 0, 0, INT32_MIN};
-    if (12 * cells + 16 > kTabBytes) return r;
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(tab);
-    const int ent_off = (4 * cells + 15) & ~15;
-    uint2* ent = reinterpret_cast<uint2*>(tab + ent_off);
-    const int rep_off = ent_off + 8 * cells;
-    const int rstride = cells | 1;
+    const bool in_lds = 12 * cells + 16 <= kTabBytes;
+    Prep r{in_lds ? MODE_O1_LDS : MODE_O1_GLOBAL, stride, 0, 0, 0};
+    uint32_t* cnt;
+    uint2* ent;
+    uint32_t* rep = nullptr;
     int R = 1;
-    while (R < 32 && rep_off + 2 * R * rstride * 4 <= kTabBytes) R <<= 1;
-    uint32_t* rep = reinterpret_cast<uint32_t*>(tab + rep_off);
-    for (int i = l; i < cells; i += 64) cnt[i] = 0;
+    const int rstride = cells | 1;
+    if (in_lds) {
+        cnt = reinterpret_cast<uint32_t*>(tab);
+        const int ent_off = (4 * cells + 15) & ~15;
+        ent = reinterpret_cast<uint2*>(tab + ent_off);
+        const int rep_off = ent_off + 8 * cells;
+        while (R < 32 && rep_off + 2 * R * rstride * 4 <= kTabBytes) R <<= 1;
+        rep = reinterpret_cast<uint32_t*>(tab + rep_off);
+        r.ent_off = ent_off;
+    } else {
+        cnt = reinterpret_cast<uint32_t*>(B.gs);
+        ent = reinterpret_cast<uint2*>(B.gs + kGsEntOff);
+    }
+    const bool packed = !in_lds && B.n < 65536 && 2 * cells + 8 <= kTabBytes;
+    if (packed) {
+        hist_o1_packed16(B.src, B.n, cnt, stride, L->dmap, reinterpret_cast<uint32_t*>(tab), cells);
+    } else {
+        for (int i = l; i < cells; i += 64) cnt[i] = 0;
+        if (!in_lds) __threadfence();  // the scratch was another block's a moment ago: write back / invalidate around each phase
+        WSYNC();
+        hist_o1(B.src, B.n, cnt, stride, L->dmap, rep, R, rstride, cells);
+    }
+    if (!in_lds) __threadfence();
     WSYNC();
-    hist_o1(B.src, B.n, cnt, stride, L->dmap, rep, R, rstride, cells);
-    r.ent_off = ent_off;
-    r.tab_len = tables_o1(cnt, ent, ns, ns, stride, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
+    if (in_lds) {
+        r.tab_len = tables_o1(cnt, ent, ns, ns, stride, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
+    } else {
+        const int G = min(64, kTabBytes / (stride * 4));  // >= 32 rows of the widest alphabet
+        r.tab_len = tables_o1_staged(cnt, ent, ns, stride, L, reinterpret_cast<uint32_t*>(tab), G, B.slot + 9, B.rcp_tab,
+                                     B.cap - 9 - 16);
+    }
+    if (!in_lds) __threadfence();
+    WSYNC();
     if (r.tab_len < 0)
         r.status = r.tab_len;
     else
@@ -1023,8 +1174,7 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
             if (order == 0) {
                 p = prep_o0(B);
             } else {
-                p = prep_o1_lds(B);
-                if (p.status == INT32_MIN) p = prep_o1_global(B);
+                p = prep_o1(B);
             }
             if (l == 0) {
                 L->mode = p.mode;
@@ -1045,7 +1195,7 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
             else if (mode == MODE_O1_LDS)
                 pay_len = stream_o1_lds(B, tab_len, stride, ent_off);
             else
-                pay_len = stream_o1_global(B, tab_len);
+                pay_len = stream_o1_global(B, tab_len, stride);
         }
         if (!helper) return;  // the epilogue belongs to the helper wave (it holds the payload length)
         if (a.prof && l == 0) {
