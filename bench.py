@@ -226,6 +226,30 @@ def cpu_baseline(w, budget_s=15.0):
                        "(%d blocks, %.1f MB raw), one container per thread at a time" % (n_c, l.size, mb)), (out, ooff, olen, n_c)
 
 
+def pmc_traffic(a):
+    """HBM bytes per rans_encode_kernel launch from the committed rocprofv3 --pmc passes (profiles/*_pmc_*.csv, taken
+    with this same command at the default sizes): 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of 16-byte
+    streaming loads at 64 bytes, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, both in KiB.  None at other sizes or
+    when the passes are missing: counters cannot be collected from inside the timed process."""
+    if (a.reads, a.ref_len, a.read_len) != (10_000_000, 64_000_000, 150):
+        return None
+    import csv
+    import glob
+    vals = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_%s.csv" % c)))
+        if not files:
+            return None
+        with open(files[-1]) as f:
+            rows = [r for r in csv.reader(l for l in f if not l.startswith("#"))]
+        for r in rows[1:]:
+            if "rans_encode_kernel" in r[0]:
+                vals[c] = float(r[2]) * 1024.0
+    if len(vals) != 2:
+        return None
+    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,7 +302,8 @@ def main():
         algo = w["raw_bytes"] + comp_bytes  # n_raw + n_comp per encoded block
         ach = algo / enc_s / 1e9
         extra["roofline"] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                                 traffic=None, kernel="rans_encode_kernel", ms_per_launch=enc_s * 1e3)
+                                 traffic=pmc_traffic(a), kernel="rans_encode_kernel", ms_per_launch=enc_s * 1e3,
+                                 algorithmic_bytes=algo)
         total_raw = w["raw_bytes"] * world
         line = dict(metric="CRAM encode hot path: uncompressed external-block payload MB/s (rANS o0/o1 + feature extraction)",
                     value=total_raw * a.steps / dt / 1e6, unit="MB/s", n_gpus=world, steps=a.steps, warmup=a.warmup,

@@ -121,7 +121,11 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        L = C.CDLL(LIB_PATH)
+        path = LIB_PATH
+        prof = os.path.join(_HERE, "libcramgpu_prof.so")  # make -C cramtools_amd/csrc prof: in-kernel cycle stamps
+        if os.environ.get("CRAMGPU_PROF") == "1" and os.path.exists(prof):
+            path = prof
+        L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res

@@ -50,6 +50,7 @@ struct alignas(16) EncFixed {
             uint4 stage[2][kHalves][64];  // [buffer][half][step*4 + state]: x_max-1, rcp_freq, bias, cmpl_freq | shift<<24 | small<<31
             uint4 xs[2][kHalves][4][4];   // [buffer][half][state][step/4]: state before each step of the batch
             uint8_t ring[kRingBytes];  // input bytes (dense symbol indices when the order-1 tables are in LDS)
+            uint32_t gflag[2][kHalves];  // [buffer][half] != 0: the half batch holds a symbol with freq < 16
             uint32_t fin[4];        // states after the last batch the chain ran
             unsigned long long cbusy, cbusy2, cgen;  // profiling runs only: cycles the chain wave spent outside barriers
         } p3;
@@ -855,9 +856,17 @@ __device__ __forceinline__ uint32_t chain_steps_asm(uint32_t x0, const uint4 (&P
 // i-1 into bytes, expands the symbols of batch i+1 into stage[(i+1)&1] and looks up the symbols of batch i+2; one
 // barrier.  Input reaches the helper through an LDS ring that is refilled with 16-byte loads a whole chunk (16
 // batches) before it is needed, so that no iteration waits for global memory.
+// In-kernel cycle stamps exist only in the profiling build (make prof -> libcramgpu_prof.so): s_memtime shares the
+// LDS counter and, being out of order, makes the compiler wait for ALL outstanding LDS reads at every use.
+#ifdef CRAMGPU_PROF_BUILD
+#define PROF_ON(p) ((p) != nullptr)
+#else
+#define PROF_ON(p) false
+#endif
 template <int MODE>
 __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* ent, int stride_, uint8_t* pend, int32_t room_,
-                                 unsigned long long* prof) {
+                                 unsigned long long* prof_) {
+    unsigned long long* prof = PROF_ON(prof_) ? prof_ : nullptr;
     EncLds* L = &lds;
     const int32_t n = UNIFORM(n_), stride = UNIFORM(stride_), room = UNIFORM(room_);  // arrive in vector registers
     const int l = lane_id();
@@ -900,9 +909,8 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
             cursor_next<MODE>(cur[h]);
             A0[h] = act0 ? expand_symbol(e0) : ident;
             const unsigned long long sm = __ballot((int32_t)A0[h].w < 0);
-            uint4 W = A0[h];
-            if (t == 0 && sm != 0) W.w |= 0x40000000u;  // bit 30 of the step-0 records: this half needs the general chain
-            L->p3.stage[0][h][slot] = W;
+            L->p3.stage[0][h][slot] = A0[h];
+            if (l == 0) L->p3.gflag[0][h] = sm != 0 ? 1u : 0u;  // this half needs the general chain
         }
 #pragma unroll
         for (int h = 0; h < kHalves; h++) {
@@ -922,11 +930,14 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
             if (i < nbatch && l < 4) {
 #pragma unroll
                 for (int h = 0; h < kHalves; h++) {
+                    // the flag word is read on its own, first: waiting for it does not wait for the sixteen records
+                    // the flag is read first and from its own word: waiting for it does not wait for the sixteen records
+                    const uint32_t fw = L->p3.gflag[buf][h];
                     uint4 P[kSteps];
 #pragma unroll
                     for (int tt = 0; tt < kSteps; tt++) P[tt] = L->p3.stage[buf][h][tt * 4 + l];
                     uint4* xs = &L->p3.xs[buf][h][l][0];
-                    const bool general = (UNIFORM(P[0].w) & 0x40000000u) != 0;
+                    const bool general = UNIFORM(fw) != 0;
                     if (prof && h == 0) busy2 += (unsigned long long)(clock64() - tb);
                     if (prof && general) ngen++;
 #ifdef HIP_SIM
@@ -949,9 +960,8 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
             for (int h = 0; h < kHalves; h++) {
                 An[h] = act2[h] ? expand_symbol(e2[h]) : ident;
                 const unsigned long long sm = __ballot((int32_t)An[h].w < 0);
-                uint4 W = An[h];
-                if (t == 0 && sm != 0) W.w |= 0x40000000u;
-                L->p3.stage[buf ^ 1][h][slot] = W;
+                L->p3.stage[buf ^ 1][h][slot] = An[h];
+                if (l == 0) L->p3.gflag[buf ^ 1][h] = sm != 0 ? 1u : 0u;
             }
             // input ring: chunk c is needed from iteration 8c - 2 on; it is written at 8c - 4 from the registers that
             // were loaded at 8c - 12, and the next chunk's loads are issued
@@ -1168,7 +1178,7 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
         uint8_t* tabdst = slot + 9;
         uint8_t* pend = slot + cap;
         Blk B{a.in + d.in_off, slot, gs, a.rcp_tab, a.prof ? a.prof + 8 * (size_t)b : nullptr, n, cap};
-        const long long t0 = a.prof ? clock64() : 0;
+        const long long t0 = PROF_ON(a.prof) ? clock64() : 0;
         if (helper) {  // phases 1 and 2; the chain wave waits at the barrier below
             Prep p;
             if (order == 0) {
@@ -1188,7 +1198,7 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
         const int32_t mode = UNIFORM(L->mode), stride = UNIFORM(L->stride), ent_off = UNIFORM(L->ent_off),
                       tab_len = UNIFORM(L->tab_len);
         int32_t pay_len = UNIFORM(L->status);
-        const long long t1 = a.prof ? clock64() : 0;
+        const long long t1 = PROF_ON(a.prof) ? clock64() : 0;
         if (pay_len == 0) {
             if (mode == MODE_O0)
                 pay_len = stream_o0(B, tab_len);
@@ -1198,7 +1208,7 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
                 pay_len = stream_o1_global(B, tab_len, stride);
         }
         if (!helper) return;  // the epilogue belongs to the helper wave (it holds the payload length)
-        if (a.prof && l == 0) {
+        if (PROF_ON(a.prof) && l == 0) {
             B.prof[0] = (unsigned long long)(t1 - t0);
             B.prof[1] = (unsigned long long)(clock64() - t1);
         }
