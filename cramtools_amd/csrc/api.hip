@@ -88,7 +88,7 @@ struct cramgpu_ctx {
     bool staged_pending = false;
     std::mutex mu;
     // rANS launch geometry
-    int tab_bytes = 0, enc_wpc = 0, dec_wpc = 0, n_waves_enc = 0, n_waves_dec = 0;
+    int tab_bytes = 0, dec_tab_bytes = 0, enc_wpc = 0, dec_wpc = 0, n_waves_enc = 0, n_waves_dec = 0;
     size_t enc_lds = 0, dec_lds = 0;
     DevBuf<uint8_t> enc_gs, dec_gs;
     DevBuf<uint32_t> rcp_tab, tickets;
@@ -169,7 +169,7 @@ int rans_run(cramgpu_ctx* c, bool encode, const uint8_t* d_in, uint8_t* d_out, c
     a.out_pos = d_out_pos;
     a.ticket = ticket;
     a.rcp_tab = c->rcp_tab.p;
-    a.tab_bytes = c->tab_bytes;
+    a.tab_bytes = encode ? c->tab_bytes : c->dec_tab_bytes;
     a.prof = nullptr;
     if (encode && c->prof_on) {  // profiling aid: per-block cycle counters, printed after a synchronising copy
         HIPCHK(c->d_prof.reserve((size_t)n * 8));
@@ -246,9 +246,11 @@ cramgpu_ctx* cramgpu_open(int32_t device_index) {
     c->tab_bytes = env_int("CRAMGPU_TAB_BYTES", 35 * 1024) & ~15;
     if (c->tab_bytes < 20 * 1024) c->tab_bytes = 20 * 1024;  // order-0 decode needs a 16 KiB slot table
     c->enc_lds = 0;  // static LDS, sized for 4 workgroups per CU (rans_enc.hip)
-    c->dec_lds = rans_decode_fixed_lds() + c->tab_bytes;
+    // decoder: 16 KiB = the order-0 slot table; order-1 rows of alphabets up to 64 symbols fit the same region
+    c->dec_tab_bytes = std::max(16 * 1024, env_int("CRAMGPU_DEC_TAB_BYTES", 16 * 1024) & ~15);
+    c->dec_lds = rans_decode_fixed_lds() + c->dec_tab_bytes;
     c->enc_wpc = std::max(1, std::min(env_int("CRAMGPU_ENC_GROUPS_PER_CU", 4), 4));
-    c->dec_wpc = std::max(1, std::min(env_int("CRAMGPU_DEC_WAVES_PER_CU", 16), (int)(lds_per_cu / (c->dec_lds + 512))));
+    c->dec_wpc = std::max(1, std::min(env_int("CRAMGPU_DEC_WAVES_PER_CU", 5), (int)(lds_per_cu / (c->dec_lds + 512))));
     c->prof_on = env_int("CRAMGPU_PROF", 0) != 0;
     c->n_waves_enc = c->n_cu * c->enc_wpc;
     c->n_waves_dec = c->n_cu * c->dec_wpc;

@@ -4,32 +4,40 @@
 //   RANS#uncompress L29-56, Frequencies#readStats_o0 L13-46, #readStats_o1 L50-106, Decoding L24-90,
 //   D04#uncompress L9-85, D14#uncompress L9-70
 //
-// Like the encoder this is a resident grid of single-wave workgroups pulling blocks from a ticket counter.
-// The four states of a stream share one byte cursor (renormalisation order rans0..rans3 per step), so a step is
-//   symbol lookup -> state update -> per-state byte need (0..2) -> ballot/popcount prefix over the four states
-//   -> byte fetch from an LDS ring holding the compressed stream -> cursor advance.
-// Order 0: lanes 0-3 own the states; slot -> (symbol, freq-1, slot-cum) comes from one 4096 x u32 LDS table.
-// Order 1: 256 contexts x 4096 slots does not fit LDS, so the cumulative tables are kept as rows of (cum, freq)
-//   over the block's dense alphabet and each state is given a 16-lane DPP row: every lane tests the slot against
-//   its own symbols, the single winner computes the next state, and a 4-step DPP OR-butterfly hands it to the
-//   row.  The next context row is addressed directly by the dense symbol index, and its fetch overlaps the
-//   renormalisation of the current step.
+// A resident grid of single-wave workgroups pulling blocks from a ticket counter.  A block is one serial chain (the
+// four states share one byte cursor, renormalisation order rans0..rans3 per step), and a lone wave issues about one
+// instruction per 5 cycles whatever it is, so the step is built to be short and to hold ONE LDS round trip:
+//   * each state lives in a 16-lane DPP row (same value in all 16 lanes);
+//   * order 0: slot -> (symbol, freq-1, slot-cum) from one 4096 x u32 LDS table;
+//   * order 1: 256 contexts x 4096 slots do not fit LDS, so a context is a row of packed (cum, freq, symbol) words
+//     over the block's dense alphabet: lane s tests the slot against symbols s, s+16, ..., a 4-step DPP OR butterfly
+//     hands the winner's word to the row, and the next context's row is fetched while the state renormalises;
+//   * renormalisation reads no memory: the 8 stream bytes at the cursor sit in a register pair that is reloaded
+//     (one unaligned LDS read from the ring of the compressed stream) only after a step that consumed bytes, and a
+//     step in which no state needs a byte (most steps of a quality block) skips it with one uniform branch;
+//   * decoded symbols stay in registers (lane j of a row keeps step j of a 16-step chunk) and leave as one byte store
+//     per lane per chunk; ring refills are 16-byte loads issued a whole refill ahead.
 #include "internal.h"
 
 namespace {
 
-constexpr int kRing = 4096;  // LDS ring of compressed bytes
+constexpr int kRing = 4096;  // LDS ring of compressed bytes (+ 16 bytes that mirror its start, for 8-byte window reads)
+constexpr int kChunk = 16;   // decode steps between ring checks / output stores
+constexpr unsigned long long kTop = 0x8000800080008000ull;  // lane 15 of each 16-lane row: one representative per state
 
 struct DecFixedLds {
-    uint8_t ring[kRing];
+    uint8_t ring[kRing + 16];
     uint8_t dmap[256];
     uint8_t syml[256];
     uint8_t present[256];
 };
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
-__device__ __forceinline__ uint32_t mbcnt(unsigned long long m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+__device__ __forceinline__ uint32_t mbcnt2(unsigned long long m1, unsigned long long m2) {
+    uint32_t a = __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u);
+    a = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), a);
+    a = __builtin_amdgcn_mbcnt_lo((uint32_t)m2, a);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), a);
 }
 
 // OR over the 16 lanes of a DPP row (butterfly: quad xor 1, quad xor 2, half mirror, row mirror)
@@ -41,31 +49,67 @@ __device__ __forceinline__ uint32_t row_or(uint32_t v) {
     return v;
 }
 
-// compressed-stream reader: bytes [fill-kRing, fill) of the stream are resident in the ring
+struct __attribute__((packed)) PackedU64 { unsigned long long v; };
+
+// compressed-stream reader: bytes [fill-kRing, fill) of the stream are resident in the ring; the next 1 KiB piece is
+// already on its way in registers (`pre`) when a refill writes the previous one
 struct Stream {
     const uint8_t* src;   // 16-byte aligned start of the stream
     int32_t len;          // stream bytes
     int32_t fill;         // multiple of 1024
     uint8_t* ring;
-    __device__ __forceinline__ void refill() {
+    uint4 pre;
+    __device__ __forceinline__ void fetch() {
         const int32_t i = fill + lane_id() * 16;
-        if (i < len) {  // the arena is padded to 16 bytes, so a partial last chunk may be read whole
-            uint4 v = *reinterpret_cast<const uint4*>(src + i);
-            *reinterpret_cast<uint4*>(ring + (i & (kRing - 1))) = v;
-        }
-        fill += 1024;
-        __syncthreads();
+        if (i < len) pre = *reinterpret_cast<const uint4*>(src + i);  // arena padded to 16 bytes: a partial last unit is read whole
     }
     __device__ __forceinline__ void reset() {
-        fill = 0;
         __syncthreads();
+        fill = 0;
+        pre = make_uint4(0, 0, 0, 0);
+        fetch();
+    }
+    __device__ __forceinline__ void refill() {
+        const int32_t pos = (fill & (kRing - 1)) + lane_id() * 16;
+        *reinterpret_cast<uint4*>(ring + pos) = pre;
+        if (pos == 0) *reinterpret_cast<uint4*>(ring + kRing) = pre;
+        fill += 1024;
+        fetch();
+        __syncthreads();
+    }
+    // make [.., upto) resident (or everything up to the end of the stream)
+    __device__ __forceinline__ void ensure(int32_t upto) {
+        while (fill < upto && fill < len) refill();
     }
     // byte at stream offset p (uniform p), sequential access
     __device__ __forceinline__ uint32_t at(int32_t p) {
         while (p >= fill) refill();
         return ring[p & (kRing - 1)];
     }
+    // the 8 stream bytes at offset p, little endian (p .. p+7 resident or beyond the end of the stream)
+    __device__ __forceinline__ unsigned long long window(int32_t p) const {
+        return reinterpret_cast<const PackedU64*>(ring + (p & (kRing - 1)))->v;
+    }
+    __device__ __forceinline__ uint32_t le32(int32_t p) const { return (uint32_t)window(p); }
 };
+
+// Decoding#RansDecRenorm for the four states of a step, in the reference's order rans0..rans3 from one shared cursor
+// (D04#uncompress L60-63, D14#uncompress L50-53).  A state lives in a 16-lane row (same value in every lane);
+// `w` holds the 8 stream bytes at `cur`: a step consumes at most 2 bytes per state.
+__device__ __forceinline__ void renorm(uint32_t& x, int32_t& cur, unsigned long long& w, const Stream& S, bool live) {
+    const bool n1 = live && x < RANS_BYTE_L;
+    const unsigned long long b1 = __ballot(n1);
+    if (b1 != 0) {  // uniform; most steps of a well-compressed block need no byte at all
+        const bool n2 = live && x < (1u << 15);
+        const unsigned long long m1 = b1 & kTop, m2 = __ballot(n2) & kTop;
+        const uint32_t a = mbcnt2(m1, m2);  // bytes taken by the states before this one
+        const uint32_t t = __builtin_bswap32((uint32_t)(w >> (8u * a)));  // first byte on top
+        const uint32_t sh = n2 ? 16u : (n1 ? 8u : 0u);
+        x = (uint32_t)((((unsigned long long)x << 32) | t) << sh >> 32);
+        cur += __popcll(m1) + __popcll(m2);
+        w = S.window(cur);
+    }
+}
 
 // Frequencies#readStats_o0 L13-46: one row.  V::sym(j, F, C) is called per listed symbol.  Returns 0 or a code.
 template <bool O1, class V>
@@ -139,104 +183,164 @@ struct MarkO1 {
     __device__ __forceinline__ void sym(int j, int, int) { present[j] = 1; }
 };
 struct FillO1 {
-    uint32_t* rows;  // [n][n] C | F<<16
+    uint32_t* rows;  // [nd][stride]: (4096 - C) & 4095 | k << 12 | (F-1) << 20, see decode_o1
     const uint8_t* dmap;
-    int n;
+    int stride;
     int cur;
-    __device__ __forceinline__ void ctx(int i) { cur = dmap[i] * n; }
+    __device__ __forceinline__ void ctx(int i) { cur = dmap[i] * stride; }
     __device__ __forceinline__ void sym(int j, int F, int C) {
-        if (lane_id() == 0) rows[cur + dmap[j]] = (uint32_t)C | ((uint32_t)F << 16);
+        if (lane_id() == 0)
+            rows[cur + dmap[j]] = ((4096u - (uint32_t)C) & 4095u) | ((uint32_t)dmap[j] << 12) | ((uint32_t)(F - 1) << 20);
     }
 };
+constexpr uint32_t kAbsent = 0xFFFFFFFFu;  // not a valid entry: it would be C = 1 with F = 4096
 
-// D04#uncompress L9-85
-__device__ int decode_o0(Stream& S, int32_t p, const uint32_t* R, uint8_t* out, int32_t n) {
+// rows[nd][stride] <- kAbsent
+__device__ __forceinline__ void rows_clear(uint32_t* rows, int total) {
+    for (int i = lane_id(); i < total; i += 64) rows[i] = kAbsent;
+}
+// every absent entry of a row becomes a copy of the row's first present entry (0 for a context the table never
+// defined: such a row is only reachable from a corrupt stream and decodes to garbage without leaving the tables)
+__device__ __forceinline__ void rows_fix(uint32_t* rows, int nd, int stride) {
     const int l = lane_id();
-    if (p + 16 > S.len) return CRAMGPU_E_CORRUPT;
-    uint32_t x = RANS_BYTE_L;
-    S.at(p);
-    while (S.fill < p + 16 && S.fill < ((S.len + 1023) & ~1023)) S.refill();
-    if (l < 4) {
-        const int32_t a = p + 4 * l;
-        x = (uint32_t)S.ring[a & (kRing - 1)] | ((uint32_t)S.ring[(a + 1) & (kRing - 1)] << 8) |
-            ((uint32_t)S.ring[(a + 2) & (kRing - 1)] << 16) | ((uint32_t)S.ring[(a + 3) & (kRing - 1)] << 24);
-    }
-    int32_t cur = p + 16;
-    const int32_t out_end = n & ~3;
-    for (int32_t i = 0; i < out_end; i += 4) {
-        if (S.fill - cur < 2048 && S.fill < S.len) S.refill();
-        const uint32_t e = R[x & 4095u];
-        if (l < 4) {
-            out[i + l] = (uint8_t)e;
-            x = (((e >> 8) & 4095u) + 1u) * (x >> 12) + (e >> 20);
+    for (int r = 0; r < nd; r++) {
+        uint32_t* row = rows + r * stride;
+        uint32_t first = 0;
+        bool found = false;
+        for (int c0 = 0; c0 < stride && !found; c0 += 64) {
+            const uint32_t v = c0 + l < stride ? row[c0 + l] : kAbsent;
+            const unsigned long long m = __ballot(v != kAbsent);
+            if (m != 0) {
+                first = __shfl(v, __ffsll((long long)m) - 1);
+                found = true;
+            }
         }
-        const bool n1 = x < RANS_BYTE_L, n2 = x < (1u << 15);
-        const unsigned long long m1 = __ballot(n1), m2 = __ballot(n2);
-        const int32_t tot = __popcll(m1) + __popcll(m2);
-        if (cur + tot > S.len) return CRAMGPU_E_CORRUPT;
-        const int32_t a = cur + (int32_t)(mbcnt(m1) + mbcnt(m2));
-        const uint32_t b0 = S.ring[a & (kRing - 1)], b1 = S.ring[(a + 1) & (kRing - 1)];
-        x = n2 ? ((x << 16) | (b0 << 8) | b1) : (n1 ? ((x << 8) | b0) : x);
-        cur += tot;
+        for (int c = l; c < stride; c += 64)
+            if (row[c] == kAbsent) row[c] = first;
     }
-    if (l < (n & 3)) out[out_end + l] = (uint8_t)R[x & 4095u];
-    return 0;
 }
 
-// D14#uncompress L9-70.  rows[n][n] over the dense alphabet (index 0 = byte 0), M = ceil(n/16).
-__device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, int nd, const uint8_t* syml, uint8_t* out,
-                         int32_t n) {
+// D04#uncompress L9-85.  R[4096]: sym | (F-1)<<8 | (slot-C)<<20.  State g = lanes 16g..16g+15.
+__device__ int decode_o0(Stream& S, int32_t p, const uint32_t* R, uint8_t* out, int32_t n) {
     const int l = lane_id();
     const int g = l >> 4, s = l & 15;
     if (p + 16 > S.len) return CRAMGPU_E_CORRUPT;
-    S.at(p);
-    while (S.fill < p + 16 && S.fill < ((S.len + 1023) & ~1023)) S.refill();
-    uint32_t x;
-    {
-        const int32_t a = p + 4 * g;
-        x = (uint32_t)S.ring[a & (kRing - 1)] | ((uint32_t)S.ring[(a + 1) & (kRing - 1)] << 8) |
-            ((uint32_t)S.ring[(a + 2) & (kRing - 1)] << 16) | ((uint32_t)S.ring[(a + 3) & (kRing - 1)] << 24);
-    }
+    S.ensure(p + 16 + 8 * kChunk + 8);
+    uint32_t x = S.le32(p + 4 * g);
     int32_t cur = p + 16;
+    unsigned long long w = S.window(cur);
+    const int32_t nsteps = n >> 2;
+    int32_t i = 0;
+    for (; i + kChunk <= nsteps; i += kChunk) {
+        S.ensure(cur + 8 * kChunk + 8);
+        if (cur > S.len) return CRAMGPU_E_CORRUPT;
+        uint32_t keep = 0;
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) {
+            const uint32_t e = R[x & 4095u];
+            keep = s == j ? e : keep;
+            x = (((e >> 8) & 4095u) + 1u) * (x >> 12) + (e >> 20);
+            renorm(x, cur, w, S, true);
+        }
+        out[4 * (i + s) + g] = (uint8_t)keep;
+    }
+    const int32_t rem = nsteps - i;
+    if (rem > 0) {
+        S.ensure(cur + 8 * kChunk + 8);
+        uint32_t keep = 0;
+        for (int j = 0; j < rem; j++) {
+            const uint32_t e = R[x & 4095u];
+            keep = s == j ? e : keep;
+            x = (((e >> 8) & 4095u) + 1u) * (x >> 12) + (e >> 20);
+            renorm(x, cur, w, S, true);
+        }
+        if (s < rem) out[4 * (i + s) + g] = (uint8_t)keep;
+    }
+    if (cur > S.len) return CRAMGPU_E_CORRUPT;
+    if (s == 0 && g < (n & 3)) out[4 * nsteps + g] = (uint8_t)R[x & 4095u];
+    return 0;
+}
+
+// D14#uncompress L9-70.  rows[nd][16*M] over the dense alphabet (index 0 = byte 0); an entry is
+//   (4096 - C) & 4095 | k << 12 | (F-1) << 20
+// so that with xa = x + entry the slot offset inside the symbol is xa & 4095 and the slot belongs to the symbol iff
+// (xa << 20) <= entry (C + F <= 4096 keeps a slot below C from aliasing).  Lane s of a state's row tests the symbols
+// s, s+16, ...; symbols a context does not have carry a copy of one it has, so every hit ORs to the same word.
+template <int MS>  // MS > 0: M known at compile time (the next row is fetched while the state is renormalised)
+__device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, int M_, const uint8_t* syml, uint8_t* out,
+                         int32_t n) {
+    const int l = lane_id();
+    const int g = l >> 4, s = l & 15;
+    const int M = MS > 0 ? MS : M_;
+    const uint32_t stride = 16u * (uint32_t)M;
+    if (p + 16 > S.len) return CRAMGPU_E_CORRUPT;
+    S.ensure(p + 16 + 8 * kChunk + 8);
+    uint32_t x = S.le32(p + 4 * g);
+    int32_t cur = p + 16;
+    unsigned long long w = S.window(cur);
     const int32_t q = n >> 2;
-    const int M = (nd + 15) >> 4;
-    const unsigned long long top = 0x8000800080008000ull;  // one representative lane per state
-    uint32_t rowbase = 0;                                   // context 0
-    int32_t o = g * q;
-    const int32_t steps = q + (n - 4 * q);                  // q common steps, then state 3 alone
-    for (int32_t i = 0; i < steps; i++, o++) {
-        if (S.fill - cur < 2048 && S.fill < S.len) S.refill();
-        const bool live = i < q || g == 3;
-        const uint32_t slot = x & 4095u, xh = x >> 12;
-        uint32_t cand = 0, symd = 0;
-        for (int m = 0; m < M; m++) {
-            const int k = s + 16 * m;
-            if (k < nd) {
-                const uint32_t cf = rows[rowbase + k];
-                const uint32_t off = slot - (cf & 0xFFFFu), F = cf >> 16;
-                if (off < F) {
-                    cand = F * xh + off;
-                    symd = (uint32_t)k;
-                }
+    uint32_t e[MS > 0 ? MS : 1];
+    uint32_t roff = (uint32_t)s;  // context 0
+    if (MS > 0) {
+#pragma unroll
+        for (int m = 0; m < MS; m++) e[m] = rows[roff + 16 * m];
+    }
+    auto step = [&](bool live) -> uint32_t {
+        uint32_t pk = 0;
+        if (MS > 0) {
+#pragma unroll
+            for (int m = 0; m < MS; m++) {
+                const uint32_t xa = x + e[m];
+                pk |= (xa << 20) <= e[m] ? ((e[m] & ~4095u) | (xa & 4095u)) : 0u;
+            }
+        } else {
+            for (int m = 0; m < M; m++) {
+                const uint32_t em = rows[roff + 16 * m];
+                const uint32_t xa = x + em;
+                pk |= (xa << 20) <= em ? ((em & ~4095u) | (xa & 4095u)) : 0u;
             }
         }
-        cand = row_or(cand);
-        symd = row_or(symd);
-        if (__ballot(live && cand == 0) != 0) return CRAMGPU_E_CORRUPT;  // context or slot absent from the tables
+        pk = row_or(pk);
+        const uint32_t k = (pk >> 12) & 255u;
         if (live) {
-            if (s == 0) out[o] = syml[symd];
-            x = cand;
-            rowbase = symd * (uint32_t)nd;
+            roff = k * stride + (uint32_t)s;
+            if (MS > 0) {
+#pragma unroll
+                for (int m = 0; m < MS; m++) e[m] = rows[roff + 16 * m];
+            }
+            x = ((pk >> 20) + 1u) * (x >> 12) + (pk & 4095u);
         }
-        const bool n1 = live && x < RANS_BYTE_L, n2 = live && x < (1u << 15);
-        const unsigned long long m1 = __ballot(n1) & top, m2 = __ballot(n2) & top;
-        const int32_t tot = __popcll(m1) + __popcll(m2);
-        if (cur + tot > S.len) return CRAMGPU_E_CORRUPT;
-        const int32_t a = cur + (int32_t)(mbcnt(m1) + mbcnt(m2));
-        const uint32_t b0 = S.ring[a & (kRing - 1)], b1 = S.ring[(a + 1) & (kRing - 1)];
-        x = n2 ? ((x << 16) | (b0 << 8) | b1) : (n1 ? ((x << 8) | b0) : x);
-        cur += tot;
+        renorm(x, cur, w, S, live);
+        return k;
+    };
+    int32_t i = 0;
+    for (; i + kChunk <= q; i += kChunk) {
+        S.ensure(cur + 8 * kChunk + 8);
+        if (cur > S.len) return CRAMGPU_E_CORRUPT;
+        uint32_t keep = 0;
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) {
+            const uint32_t k = step(true);
+            keep = s == j ? k : keep;
+        }
+        out[g * q + i + s] = syml[keep];
     }
+    // the last q % 16 common steps, then the n - 4q bytes that only state 3 decodes
+    const int32_t total = q + (n - 4 * q);
+    while (i < total) {
+        S.ensure(cur + 8 * kChunk + 8);
+        if (cur > S.len) return CRAMGPU_E_CORRUPT;
+        const int32_t cnt = total - i < kChunk ? total - i : kChunk;
+        uint32_t keep = 0;
+        for (int j = 0; j < cnt; j++) {
+            const bool live = i + j < q || g == 3;
+            const uint32_t k = step(live);
+            keep = s == j ? k : keep;
+        }
+        if (s < cnt && (i + s < q || g == 3)) out[g * q + i + s] = syml[keep];
+        i += cnt;
+    }
+    if (cur > S.len) return CRAMGPU_E_CORRUPT;
     return 0;
 }
 
@@ -269,7 +373,7 @@ __device__ void decode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* g
         } else if (raw == 0) {
             result = 0;
         } else {
-            Stream S{src, len, 0, L->ring};
+            Stream S{src, len, 0, L->ring, make_uint4(0, 0, 0, 0)};
             S.reset();
             int32_t p = 9;
             int rc;
@@ -304,27 +408,40 @@ __device__ void decode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* g
                     }
                     nd = __shfl(nd, 0);
                     __syncthreads();
-                    const bool in_lds = nd * nd * 4 <= a.tab_bytes;
+                    const int M = (nd + 15) >> 4, stride = 16 * M;
+                    const bool in_lds = nd * stride * 4 <= a.tab_bytes;
                     uint32_t* rows = in_lds ? reinterpret_cast<uint32_t*>(tab) : reinterpret_cast<uint32_t*>(gs);
-                    if (in_lds) {
-                        uint32_t* r = reinterpret_cast<uint32_t*>(tab);
-                        for (int i = l; i < nd * nd; i += 64) r[i] = 0;
-                    } else {
-                        uint32_t* r = reinterpret_cast<uint32_t*>(gs);
-                        for (int i = l; i < nd * nd; i += 64) r[i] = 0;
-                    }
+                    if (in_lds)
+                        rows_clear(reinterpret_cast<uint32_t*>(tab), nd * stride);
+                    else
+                        rows_clear(reinterpret_cast<uint32_t*>(gs), nd * stride);
                     __threadfence();
                     __syncthreads();
                     S.reset();
-                    FillO1 v{rows, L->dmap, nd, 0};
+                    FillO1 v{rows, L->dmap, stride, 0};
                     rc = read_rows_o1(S, p, v);
                     __threadfence();
                     __syncthreads();
                     if (!rc) {
-                        if (in_lds)
-                            rc = decode_o1(S, p, reinterpret_cast<uint32_t*>(tab), nd, L->syml, out, raw);
-                        else
-                            rc = decode_o1(S, p, reinterpret_cast<uint32_t*>(gs), nd, L->syml, out, raw);
+                        if (in_lds) {
+                            uint32_t* r = reinterpret_cast<uint32_t*>(tab);
+                            rows_fix(r, nd, stride);
+                            __syncthreads();
+                            if (M == 1)
+                                rc = decode_o1<1>(S, p, r, M, L->syml, out, raw);
+                            else if (M == 2)
+                                rc = decode_o1<2>(S, p, r, M, L->syml, out, raw);
+                            else if (M == 3)
+                                rc = decode_o1<3>(S, p, r, M, L->syml, out, raw);
+                            else
+                                rc = decode_o1<0>(S, p, r, M, L->syml, out, raw);
+                        } else {
+                            uint32_t* r = reinterpret_cast<uint32_t*>(gs);
+                            rows_fix(r, nd, stride);
+                            __threadfence();
+                            __syncthreads();
+                            rc = decode_o1<0>(S, p, r, M, L->syml, out, raw);
+                        }
                     }
                 }
             }
