@@ -167,6 +167,80 @@ class Step:
             self.enc_ms.append(self.ev[0].elapsed_time(self.ev[1]))
 
 
+class DecodeStep:
+    """configs[2]: the decode hot path over the streams one encode step produced (nothing allocated while timed):
+      K2  rANS decode of every external block (from the gathered dense arena back into a raw arena),
+      N1  CramNormalizer.restoreReadBases for every read (features + substitution codes of the encode step,
+          whole-reference window per container, matrices on the host as the compression header holds them),
+      N2  CramNormalizer.restoreQualityScores on the decoded QS bytes (force-preserved scores)."""
+
+    def __init__(self, dev, eng, w, enc):
+        self.dev, self.eng, self.w, self.enc = dev, eng, w, enc
+        n = w["n_blocks"]
+        lens = enc.d_len.cpu().numpy().astype(np.int64)
+        offs = enc.d_pack_off.cpu().numpy().astype(np.int64)
+        self.blocks = (_lib.Block * n)()
+        for i in range(n):
+            b = w["blocks"][i]
+            self.blocks[i] = _lib.Block(int(offs[i]), b.in_off, int(lens[i]), b.in_len, 0, 0)
+        self.d_raw = torch.zeros(w["d_in"].numel(), dtype=torch.uint8, device=dev)
+        self.d_len = torch.zeros(n, dtype=torch.int32, device=dev)
+        reads = w["reads"]
+        self.mats_h = np.ascontiguousarray(enc.mats.cpu().numpy())
+        self.bases = torch.zeros(reads.bases.numel() + 16, dtype=torch.uint8, device=dev)
+        self.st_b = torch.zeros(reads.n, dtype=torch.int32, device=dev)
+        self.st_q = torch.zeros(reads.n, dtype=torch.int32, device=dev)
+        self.rflags = reads.rflags | 16  # CRAMGPU_RF_FORCE_QS: lossless records carry CF_FORCE_PRESERVE_QS
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        self.k2_ms, self.ms = [], []
+
+    def run(self, timed=True):
+        w, L, reads = self.w, _lib.lib(), self.w["reads"]
+        s = torch.cuda.current_stream().cuda_stream
+        if timed:
+            self.ev[0].record()
+        self.eng.decode_dev(self.enc.d_pack, self.d_raw, self.blocks, w["n_blocks"], self.d_len)
+        if timed:
+            self.ev[1].record()
+        fs = self.enc.feats.struct()
+        _lib.check(L.cramgpu_restore_bases_dev(
+            self.eng.handle, reads.n, reads.read_len.data_ptr(), reads.aln_start.data_ptr(), self.rflags.data_ptr(),
+            reads.read_cont.data_ptr(), reads.n_cont, reads.win.data_ptr(), C.byref(fs), reads.bases.data_ptr(),
+            reads.base_off.data_ptr(), w["ref"].data_ptr(), self.mats_h.ctypes.data, self.bases.data_ptr(),
+            reads.base_off.data_ptr(), self.st_b.data_ptr(), s))
+        # the qualities of a read sit in the decoded arena inside its container's QS block (q_off), restored in place
+        _lib.check(L.cramgpu_restore_quals_dev(self.eng.handle, reads.n, reads.read_len.data_ptr(), self.rflags.data_ptr(),
+                                               C.byref(fs), 30, self.d_raw.data_ptr(), self.q_off.data_ptr(),
+                                               self.st_q.data_ptr(), s))
+        if timed:
+            self.ev[2].record()
+            torch.cuda.synchronize()
+            self.k2_ms.append(self.ev[0].elapsed_time(self.ev[1]))
+            self.ms.append(self.ev[0].elapsed_time(self.ev[2]))
+
+    def prepare(self):
+        """Per-read offsets of the quality bytes inside the decoded arena (QS block of the read's container)."""
+        w, reads = self.w, self.w["reads"]
+        ns = len(SERIES)
+        qs_off = torch.as_tensor(np.array([w["blocks"][c * ns].in_off for c in range(w["n_cont"])], np.int64), device=self.dev)
+        first = reads.base_off[torch.arange(w["n_cont"], device=self.dev) * READS_PER_CONTAINER]
+        cont = reads.read_cont.to(torch.int64)
+        self.q_off = qs_off[cont] + (reads.base_off - first[cont])
+
+    def verify(self):
+        w, reads = self.w, self.w["reads"]
+        n = w["d_in"].numel() - 16
+        assert bool((self.d_len.cpu().numpy() == np.array([w["blocks"][i].in_len for i in range(w["n_blocks"])])).all()), \
+            "a block failed to decode"
+        assert torch.equal(self.d_raw[:n], w["d_in"][:n]), "decoded blocks differ from the raw arena"
+        tot = int(w["rs"].read_len.sum().item())
+        assert int((self.st_b != 0).sum().item()) == 0, "restoreReadBases reported a status"
+        assert int((self.st_q != 0).sum().item()) == 0, "restoreQualityScores reported a status"
+        assert torch.equal(self.bases[:tot], reads.bases[:tot]), "restored bases differ from the reads"
+        return "all %d blocks and %d reads round-trip (decoded arena == raw arena, restored bases == read bases)" % (
+            w["n_blocks"], reads.n)
+
+
 def cpu_baseline(w, budget_s=15.0):
     """The CPU oracle (C restatement of htsjdk 2.4.1 rANS, oracle/rans4x8.c) on a bounded sample of the same blocks."""
     from oracle import orc
@@ -259,6 +333,7 @@ def main():
     ap.add_argument("--ref-len", type=int, default=64_000_000)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -282,6 +357,16 @@ def main():
     dt = sharding.timed_region(lambda: step.run(True), a.steps, dist=dist if world > 1 else None,
                                sync=torch.cuda.synchronize)
 
+    # decode leg (configs[2]) on rank 0, outside the timed region of the headline metric
+    dec, dec_parity = None, None
+    if rank == 0 and not a.no_decode:
+        dec = DecodeStep(dev, eng, w, step)
+        dec.prepare()
+        for _ in range(1 + a.steps):
+            dec.run()
+        dec.k2_ms, dec.ms = dec.k2_ms[1:], dec.ms[1:]
+        dec_parity = dec.verify()
+
     # parity verdict on this rank's blocks: no negative lengths, and the sampled containers equal the CPU oracle
     lens = step.d_len.cpu().numpy()
     assert (lens >= 0).all(), "a block failed to encode: %r" % (lens[lens < 0][:8],)
@@ -304,6 +389,14 @@ def main():
         extra["roofline"] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                                  traffic=pmc_traffic(a), kernel="rans_encode_kernel", ms_per_launch=enc_s * 1e3,
                                  algorithmic_bytes=algo)
+        if dec is not None:
+            k2_s, dec_s = float(np.mean(dec.k2_ms)) / 1e3, float(np.mean(dec.ms)) / 1e3
+            extra["decode"] = dict(workload="configs[2]: rANS decode of the same %d blocks + restoreReadBases / "
+                                            "restoreQualityScores of the %d reads (timed outside the K steps)" % (w["n_blocks"], a.reads),
+                                   value=w["raw_bytes"] / dec_s / 1e6, unit="MB/s", reads_per_s=a.reads / dec_s,
+                                   ms_per_step=dec_s * 1e3, rans_decode_kernel_ms=k2_s * 1e3,
+                                   rans_decode_GBps=algo / k2_s / 1e9, rans_decode_frac_of_hbm=algo / k2_s / 1e9 / HBM_PEAK_GBS,
+                                   parity=dec_parity)
         total_raw = w["raw_bytes"] * world
         line = dict(metric="CRAM encode hot path: uncompressed external-block payload MB/s (rANS o0/o1 + feature extraction)",
                     value=total_raw * a.steps / dt / 1e6, unit="MB/s", n_gpus=world, steps=a.steps, warmup=a.warmup,

@@ -108,7 +108,7 @@ def test_records_gpu_random_bodies(hostsim, orc, monkeypatch):
 
 @SLOW
 def test_bench_step_on_host_build(hostsim, orc, monkeypatch):
-    """One untimed bench step end to end (K3 + matrices + codes + rANS encode + gather) on a 2-container workload."""
+    """One untimed bench step end to end (K3 + matrices + codes + rANS encode + gather, then the decode leg) on a 2-container workload."""
     import bench
     from cramtools_amd import external_compression as xc
     monkeypatch.setattr(bench, "READS_PER_CONTAINER", 300)
@@ -128,5 +128,10 @@ def test_bench_step_on_host_build(hostsim, orc, monkeypatch):
             want = orc.rans(d_in[b.in_off:b.in_off + b.in_len].tobytes(), b.order)
             assert step.d_out[int(pos[i]):int(pos[i]) + int(lens[i])].numpy().tobytes() == want, i
             assert step.d_pack[int(off[i]):int(off[i]) + int(lens[i])].numpy().tobytes() == want, i
+        # the decode leg (configs[2]): rANS decode + restoreReadBases + restoreQualityScores round-trip
+        dec = bench.DecodeStep("cpu", eng, w, step)
+        dec.prepare()
+        dec.run(False)
+        assert "round-trip" in dec.verify()
     finally:
         eng.close()
