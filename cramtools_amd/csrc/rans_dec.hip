@@ -12,21 +12,22 @@
 //   * order 1: 256 contexts x 4096 slots do not fit LDS, so a context is a row of packed (cum, freq, symbol) words
 //     over the block's dense alphabet: lane s tests the slot against symbols s, s+16, ..., a 4-step DPP OR butterfly
 //     hands the winner's word to the row, and the next context's row is fetched while the state renormalises;
-//   * renormalisation reads no memory: the 8 stream bytes at the cursor sit in a register pair that is reloaded
-//     (one unaligned LDS read from the ring of the compressed stream) only after a step that consumed bytes, and a
-//     step in which no state needs a byte (most steps of a quality block) skips it with one uniform branch;
+//   * renormalisation waits for no memory: the 8 stream bytes at the cursor sit in a register pair that is reloaded
+//     (one unaligned global load, on the vector-memory counter so that a wait for a table row never waits for it)
+//     only after a step that consumed bytes; a step in which no state needs a byte (most steps of a quality block)
+//     skips it with one uniform branch, and the usual case of at most one byte per state has a short path;
 //   * decoded symbols stay in registers (lane j of a row keeps step j of a 16-step chunk) and leave as one byte store
-//     per lane per chunk; ring refills are 16-byte loads issued a whole refill ahead.
+//     per lane per chunk.
 #include "internal.h"
 
 namespace {
 
-constexpr int kRing = 4096;  // LDS ring of compressed bytes (+ 16 bytes that mirror its start, for 8-byte window reads)
+constexpr int kRing = 4096;  // LDS ring of compressed bytes (frequency-table parse)
 constexpr int kChunk = 16;   // decode steps between ring checks / output stores
 constexpr unsigned long long kTop = 0x8000800080008000ull;  // lane 15 of each 16-lane row: one representative per state
 
 struct DecFixedLds {
-    uint8_t ring[kRing + 16];
+    uint8_t ring[kRing];
     uint8_t dmap[256];
     uint8_t syml[256];
     uint8_t present[256];
@@ -42,17 +43,31 @@ __device__ __forceinline__ uint32_t mbcnt2(unsigned long long m1, unsigned long 
 
 // OR over the 16 lanes of a DPP row (butterfly: quad xor 1, quad xor 2, half mirror, row mirror)
 __device__ __forceinline__ uint32_t row_or(uint32_t v) {
+#ifdef HIP_SIM
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+#else
+    // a DPP source written by the preceding vector instruction needs two wait states (the compiler cannot see into
+    // the asm, so the first s_nop is ours as well)
+    asm("s_nop 1\n\t"
+        "v_or_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_or_b32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_or_b32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_or_b32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+#endif
     return v;
 }
 
 struct __attribute__((packed)) PackedU64 { unsigned long long v; };
 
-// compressed-stream reader: bytes [fill-kRing, fill) of the stream are resident in the ring; the next 1 KiB piece is
-// already on its way in registers (`pre`) when a refill writes the previous one
+// reader of the frequency tables: bytes [fill-kRing, fill) of the stream are resident in the ring; the next 1 KiB
+// piece is already on its way in registers (`pre`) when a refill writes the previous one
 struct Stream {
     const uint8_t* src;   // 16-byte aligned start of the stream
     int32_t len;          // stream bytes
@@ -72,43 +87,75 @@ struct Stream {
     __device__ __forceinline__ void refill() {
         const int32_t pos = (fill & (kRing - 1)) + lane_id() * 16;
         *reinterpret_cast<uint4*>(ring + pos) = pre;
-        if (pos == 0) *reinterpret_cast<uint4*>(ring + kRing) = pre;
         fill += 1024;
         fetch();
         __syncthreads();
-    }
-    // make [.., upto) resident (or everything up to the end of the stream)
-    __device__ __forceinline__ void ensure(int32_t upto) {
-        while (fill < upto && fill < len) refill();
     }
     // byte at stream offset p (uniform p), sequential access
     __device__ __forceinline__ uint32_t at(int32_t p) {
         while (p >= fill) refill();
         return ring[p & (kRing - 1)];
     }
-    // the 8 stream bytes at offset p, little endian (p .. p+7 resident or beyond the end of the stream)
-    __device__ __forceinline__ unsigned long long window(int32_t p) const {
-        return reinterpret_cast<const PackedU64*>(ring + (p & (kRing - 1)))->v;
-    }
-    __device__ __forceinline__ uint32_t le32(int32_t p) const { return (uint32_t)window(p); }
 };
+
+#ifdef HIP_SIM
+#define UNIFORM(x) (x)
+#else
+#define UNIFORM(x) __builtin_amdgcn_readfirstlane((int)(x))
+#endif
+
+// The payload is read straight from global memory (vector memory counter), the tables from LDS (LDS counter): a wait
+// for a table row then never waits for a window that a renormalisation requested after it.
+struct Payload {
+    const uint8_t* src;  // uniform
+    int32_t len;         // uniform
+    // the 8 stream bytes at offset p, little endian; clamped so that a corrupt stream cannot walk out of the arena
+    // (the arena has 16 bytes of padding behind the last stream)
+    __device__ __forceinline__ unsigned long long window(int32_t p) const {
+        const int32_t c = p < len ? p : len;
+#ifdef HIP_SIM
+        return reinterpret_cast<const PackedU64*>(src + c)->v;
+#else
+        // an explicit global pointer: a flat load would count on the LDS counter as well
+        typedef const __attribute__((address_space(1))) PackedU64* GPtr;
+        return ((GPtr)(unsigned long long)(src + c))->v;
+#endif
+    }
+};
+__device__ __forceinline__ const uint8_t* uniform_ptr(const uint8_t* p) {
+    const unsigned long long v = (unsigned long long)p;
+    return (const uint8_t*)(((unsigned long long)(uint32_t)UNIFORM((uint32_t)(v >> 32)) << 32) | (uint32_t)UNIFORM((uint32_t)v));
+}
 
 // Decoding#RansDecRenorm for the four states of a step, in the reference's order rans0..rans3 from one shared cursor
 // (D04#uncompress L60-63, D14#uncompress L50-53).  A state lives in a 16-lane row (same value in every lane);
 // `w` holds the 8 stream bytes at `cur`: a step consumes at most 2 bytes per state.
-__device__ __forceinline__ void renorm(uint32_t& x, int32_t& cur, unsigned long long& w, const Stream& S, bool live) {
+__device__ __forceinline__ void renorm(uint32_t& x, int32_t& cur, unsigned long long& w, const Payload& P, bool live) {
     const bool n1 = live && x < RANS_BYTE_L;
     const unsigned long long b1 = __ballot(n1);
     if (b1 != 0) {  // uniform; most steps of a well-compressed block need no byte at all
         const bool n2 = live && x < (1u << 15);
-        const unsigned long long m1 = b1 & kTop, m2 = __ballot(n2) & kTop;
-        const uint32_t a = mbcnt2(m1, m2);  // bytes taken by the states before this one
-        const uint32_t t = __builtin_bswap32((uint32_t)(w >> (8u * a)));  // first byte on top
-        const uint32_t sh = n2 ? 16u : (n1 ? 8u : 0u);
+        const unsigned long long b2 = __ballot(n2);
+        const unsigned long long m1 = b1 & kTop;
+        uint32_t a = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+        int32_t tot = __popcll(m1);
+        uint32_t sh = n1 ? 8u : 0u;
+        if (b2 != 0) {  // some state needs a second byte (that takes a symbol of frequency < 16)
+            const unsigned long long m2 = b2 & kTop;
+            a = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, a));
+            tot += __popcll(m2);
+            sh = n2 ? 16u : sh;
+        }
+        const uint32_t t = __builtin_bswap32((uint32_t)(w >> (8u * a)));  // this state's first byte on top
         x = (uint32_t)((((unsigned long long)x << 32) | t) << sh >> 32);
-        cur += __popcll(m1) + __popcll(m2);
-        w = S.window(cur);
+        cur += tot;
+        w = P.window(cur);
     }
+}
+
+// lane s of a row takes the value of lane s-1, lane 0 takes v: after 16 calls lane s holds the v of 15-s calls ago
+__device__ __forceinline__ uint32_t row_push(uint32_t keep, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)keep, 0x111, 0xF, 0xF, false);  // row_shr:1
 }
 
 // Frequencies#readStats_o0 L13-46: one row.  V::sym(j, F, C) is called per listed symbol.  Returns 0 or a code.
@@ -225,34 +272,32 @@ __device__ int decode_o0(Stream& S, int32_t p, const uint32_t* R, uint8_t* out, 
     const int l = lane_id();
     const int g = l >> 4, s = l & 15;
     if (p + 16 > S.len) return CRAMGPU_E_CORRUPT;
-    S.ensure(p + 16 + 8 * kChunk + 8);
-    uint32_t x = S.le32(p + 4 * g);
-    int32_t cur = p + 16;
-    unsigned long long w = S.window(cur);
+    const Payload P{uniform_ptr(S.src), UNIFORM(S.len)};
+    uint32_t x = (uint32_t)P.window(p + 4 * g);
+    int32_t cur = UNIFORM(p) + 16;
+    unsigned long long w = P.window(cur);
     const int32_t nsteps = n >> 2;
     int32_t i = 0;
     for (; i + kChunk <= nsteps; i += kChunk) {
-        S.ensure(cur + 8 * kChunk + 8);
         if (cur > S.len) return CRAMGPU_E_CORRUPT;
         uint32_t keep = 0;
 #pragma unroll
         for (int j = 0; j < kChunk; j++) {
             const uint32_t e = R[x & 4095u];
-            keep = s == j ? e : keep;
+            keep = row_push(keep, e);
             x = (((e >> 8) & 4095u) + 1u) * (x >> 12) + (e >> 20);
-            renorm(x, cur, w, S, true);
+            renorm(x, cur, w, P, true);
         }
-        out[4 * (i + s) + g] = (uint8_t)keep;
+        out[4 * (i + 15 - s) + g] = (uint8_t)keep;
     }
     const int32_t rem = nsteps - i;
     if (rem > 0) {
-        S.ensure(cur + 8 * kChunk + 8);
         uint32_t keep = 0;
         for (int j = 0; j < rem; j++) {
             const uint32_t e = R[x & 4095u];
             keep = s == j ? e : keep;
             x = (((e >> 8) & 4095u) + 1u) * (x >> 12) + (e >> 20);
-            renorm(x, cur, w, S, true);
+            renorm(x, cur, w, P, true);
         }
         if (s < rem) out[4 * (i + s) + g] = (uint8_t)keep;
     }
@@ -274,10 +319,10 @@ __device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, int M_, con
     const int M = MS > 0 ? MS : M_;
     const uint32_t stride = 16u * (uint32_t)M;
     if (p + 16 > S.len) return CRAMGPU_E_CORRUPT;
-    S.ensure(p + 16 + 8 * kChunk + 8);
-    uint32_t x = S.le32(p + 4 * g);
-    int32_t cur = p + 16;
-    unsigned long long w = S.window(cur);
+    const Payload P{uniform_ptr(S.src), UNIFORM(S.len)};
+    uint32_t x = (uint32_t)P.window(p + 4 * g);
+    int32_t cur = UNIFORM(p) + 16;
+    unsigned long long w = P.window(cur);
     const int32_t q = n >> 2;
     uint32_t e[MS > 0 ? MS : 1];
     uint32_t roff = (uint32_t)s;  // context 0
@@ -310,25 +355,22 @@ __device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, int M_, con
             }
             x = ((pk >> 20) + 1u) * (x >> 12) + (pk & 4095u);
         }
-        renorm(x, cur, w, S, live);
+        renorm(x, cur, w, P, live);
         return k;
     };
     int32_t i = 0;
     for (; i + kChunk <= q; i += kChunk) {
-        S.ensure(cur + 8 * kChunk + 8);
         if (cur > S.len) return CRAMGPU_E_CORRUPT;
         uint32_t keep = 0;
 #pragma unroll
         for (int j = 0; j < kChunk; j++) {
-            const uint32_t k = step(true);
-            keep = s == j ? k : keep;
+            keep = row_push(keep, step(true));
         }
-        out[g * q + i + s] = syml[keep];
+        out[g * q + i + 15 - s] = syml[keep];
     }
     // the last q % 16 common steps, then the n - 4q bytes that only state 3 decodes
     const int32_t total = q + (n - 4 * q);
     while (i < total) {
-        S.ensure(cur + 8 * kChunk + 8);
         if (cur > S.len) return CRAMGPU_E_CORRUPT;
         const int32_t cnt = total - i < kChunk ? total - i : kChunk;
         uint32_t keep = 0;

@@ -158,10 +158,12 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, boo
         s = (l & ~7) | (7 - (l & 7));
     else if (ctrl == 0x140)
         s = (l & ~15) | (15 - (l & 15));
+    else if (ctrl >= 0x111 && ctrl <= 0x11F)  // row_shr:n, bound_ctrl off: lanes without a source keep `old`
+        s = (l & 15) >= (ctrl - 0x110) ? l - (ctrl - 0x110) : -1;
     else
         abort();
-    (void)old;
-    return (int)(uint32_t)hipsim::exchange((uint32_t)src, s);
+    int r = (int)(uint32_t)hipsim::exchange((uint32_t)src, s);
+    return s < 0 ? old : r;
 }
 inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
