@@ -191,6 +191,143 @@ __global__ __launch_bounds__(256) void extract_kernel(cramgpu_reads R, const uin
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K3 for short reads (Illumina-like, max_read_len <= kLaneReadMax): one LANE per read.  A match run is compared 16
+// bases at a time (one unaligned 16-byte load of the read, one of the reference window); build/Utils#normalizeBase
+// runs on four bases at once: h = (base >> 1) & 7 sends A C G T N (either case) to distinct slots of an 8-entry byte
+// table held in two registers (v_perm_b32), and a base whose table entry differs from it in more than the case bit
+// becomes 'N'.  A lane emits its own read's features in order, so nothing has to be compacted across lanes; the
+// wave-per-tile kernel above spends ~100 wave instructions per read, this one about 8.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kLaneReadMax = 1024;
+
+struct __attribute__((packed)) PackedU32x4 { uint32_t v[4]; };
+
+// byte c of the result = byte sel[c] (0..7) of {hi:lo}
+__device__ __forceinline__ uint32_t perm8(uint32_t hi, uint32_t lo, uint32_t sel) {
+#ifdef HIP_SIM
+    const unsigned long long pool = ((unsigned long long)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int c = 0; c < 4; c++) r |= (uint32_t)((pool >> (8 * ((sel >> (8 * c)) & 7))) & 255u) << (8 * c);
+    return r;
+#else
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#endif
+}
+// normalizeBase on four bases
+__device__ __forceinline__ uint32_t normalize4(uint32_t x) {
+    const uint32_t y = perm8(0x4E000000u, 0x47544341u, (x >> 1) & 0x07070707u);  // slots: A C T G - - - N
+    const uint32_t d = (y ^ x) & 0xDFDFDFDFu;                                     // nonzero byte: not that letter
+    const uint32_t nz = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
+    const uint32_t m = (nz >> 7) * 255u;
+    return (y & ~m) | (0x4E4E4E4Eu & m);
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void extract_lane_kernel(cramgpu_reads R, const uint8_t* ref, cramgpu_features F,
+                                                           int64_t* sub_hist, int32_t* counts) {
+    const int stride = (int)(gridDim.x * blockDim.x);
+    for (int r = (int)(blockIdx.x * blockDim.x + threadIdx.x); r < R.n_reads; r += stride) {
+        const int32_t fl = R.rflags[r];
+        const int32_t start = R.aln_start[r];
+        const bool mapped = !(fl & (CRAMGPU_RF_UNMAPPED | CRAMGPU_RF_SKIP)) && start != 0;
+        int64_t nf = 0;
+        if (mapped) {
+            const int cont = R.read_cont ? R.read_cont[r] : 0;
+            const cramgpu_refwin W = R.win[cont];
+            const int64_t o = WRITE ? F.off[r] : 0;
+            const uint8_t* wref = ref + W.ref_off;
+            const int64_t boff = R.base_off[r];
+            const uint8_t* rb = R.bases + boff;
+            const bool nobases = (fl & CRAMGPU_RF_NO_BASES) != 0;
+            const uint32_t* cg = R.cigar + R.cigar_off[r];
+            const int nc = R.n_cigar[r];
+            int pos = 0, refoff = 0;
+            for (int e = 0; e < nc; e++) {
+                const uint32_t ce = cg[e];
+                const int op = (int)(ce & 15u), len = (int)(ce >> 4);
+                if (op == OP_D || op == OP_N || op == OP_P || op == OP_H || op == OP_S) {
+                    if (WRITE) {
+                        const int64_t i = o + nf;
+                        F.op[i] = op == OP_D ? 'D' : op == OP_N ? 'N' : op == OP_P ? 'P' : op == OP_H ? 'H' : 'S';
+                        F.pos[i] = pos + 1;
+                        F.a[i] = op == OP_S ? pos : len;
+                        F.b[i] = op == OP_S ? len : 0;
+                    }
+                    nf += 1;
+                } else if (op == OP_I) {
+                    if (WRITE) {
+                        for (int i = 0; i < len; i++) {
+                            const int64_t x = o + nf + i;
+                            F.op[x] = 'i';
+                            F.pos[x] = pos + 1 + i;
+                            F.a[x] = nobases ? 'N' : rb[pos + i];
+                            F.b[x] = 0;
+                        }
+                    }
+                    nf += len;
+                } else if (op == OP_M || op == OP_EQ || op == OP_X) {
+                    const int64_t rc0 = (int64_t)start + refoff - 1 - W.ref_start0;  // window index of the run's base 0
+                    for (int i0 = 0; i0 < len; i0 += 16) {
+                        const int n = len - i0 < 16 ? len - i0 : 16;
+                        const int64_t rc = rc0 + i0;
+                        uint32_t b[4], rr[4];
+                        if (nobases) {
+                            b[0] = b[1] = b[2] = b[3] = 0x4E4E4E4Eu;
+                        } else if (boff + pos + i0 + 16 <= R.n_bases) {  // a whole unit lies inside the base arena
+                            const PackedU32x4 t = *reinterpret_cast<const PackedU32x4*>(rb + pos + i0);
+                            b[0] = t.v[0], b[1] = t.v[1], b[2] = t.v[2], b[3] = t.v[3];
+                        } else {
+                            b[0] = b[1] = b[2] = b[3] = 0;
+                            for (int j = 0; j < n; j++) b[j >> 2] |= (uint32_t)rb[pos + i0 + j] << (8 * (j & 3));
+                        }
+                        if (rc >= 0 && rc + 16 <= W.ref_len) {
+                            const PackedU32x4 t = *reinterpret_cast<const PackedU32x4*>(wref + rc);
+                            rr[0] = t.v[0], rr[1] = t.v[1], rr[2] = t.v[2], rr[3] = t.v[3];
+                        } else {  // the run leaves the window: bases outside it read as 'N'
+                            rr[0] = rr[1] = rr[2] = rr[3] = 0;
+                            for (int j = 0; j < 16; j++) {
+                                const int64_t q = rc + j;
+                                const uint32_t v = (j < n && q >= 0 && q < W.ref_len) ? wref[q] : (uint32_t)'N';
+                                rr[j >> 2] |= v << (8 * (j & 3));
+                            }
+                        }
+                        uint32_t any = 0, diff[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            rr[c] = normalize4(rr[c]);
+                            diff[c] = b[c] ^ rr[c];
+                            const int left = n - 4 * c;  // bases of this word inside the run
+                            if (left < 4) diff[c] &= left <= 0 ? 0u : (1u << (8 * left)) - 1u;
+                            any |= diff[c];
+                        }
+                        if (any == 0) continue;
+                        for (int j = 0; j < n; j++) {
+                            if (((diff[j >> 2] >> (8 * (j & 3))) & 255u) == 0) continue;
+                            const uint8_t bj = (uint8_t)(b[j >> 2] >> (8 * (j & 3)));
+                            const uint8_t refb = (uint8_t)(rr[j >> 2] >> (8 * (j & 3)));
+                            if (WRITE) {
+                                const int64_t x = o + nf;
+                                F.op[x] = 'X';
+                                F.pos[x] = pos + i0 + j + 1;
+                                F.a[x] = (int32_t)bj | ((int32_t)refb << 8) | (0xFF << 16);
+                                F.b[x] = 0;
+                                const int bi = acgtn_index(bj);
+                                if (sub_hist && bi >= 0)
+                                    atomicAdd((unsigned long long*)&sub_hist[(int64_t)cont * 25 + acgtn_index(refb) * 5 + bi], 1ull);
+                            }
+                            nf += 1;
+                        }
+                    }
+                }
+                if (consumes_read(op)) pos += len;
+                if (consumes_ref(op)) refoff += len;
+            }
+        }
+        if (!WRITE) counts[r] = (int32_t)nf;
+    }
+}
+
 // Exclusive scan of int32 counts into int64 offsets (off[n] = total) in three launches: per-tile sums, scan of the
 // tile sums by one workgroup, per-tile scan with the tile's base.  A tile is 256 threads x 16 consecutive counts.
 constexpr int kScanThreads = 256, kScanPer = 16, kScanTile = kScanThreads * kScanPer;
@@ -729,6 +866,15 @@ static int grid_for_waves(int64_t n_items, int waves_per_block) {
 
 hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
                                    int32_t* d_counts, bool write_pass, hipStream_t s) {
+    if (r.max_read_len <= kLaneReadMax) {  // short reads: a lane per read
+        int64_t blocks = ((int64_t)r.n_reads + 255) / 256;
+        const int grid = (int)(blocks < 1 ? 1 : blocks > 256 * 32 ? 256 * 32 : blocks);
+        if (write_pass)
+            hipLaunchKernelGGL(extract_lane_kernel<true>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts);
+        else
+            hipLaunchKernelGGL(extract_lane_kernel<false>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts);
+        return hipGetLastError();
+    }
     const int grid = grid_for_waves(((int64_t)r.n_reads + 63) / 64, 4);  // a wave per tile of 64 reads
     if (write_pass)
         hipLaunchKernelGGL(extract_kernel<true>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts);
