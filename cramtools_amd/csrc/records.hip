@@ -474,7 +474,13 @@ __global__ __launch_bounds__(256) void restore_bases_kernel(int32_t n_reads, con
                                                             const int64_t* out_off, int32_t* status) {
     const int lane = threadIdx.x & 63;
     const int n_waves = wave_count();
-    for (int r = wave_index(); r < n_reads; r += n_waves) {
+    const int n_tiles = (n_reads + 63) >> 6;
+    for (int tile = wave_index(); tile < n_tiles; tile += n_waves) {
+      // short reads belong to the lane-per-read kernel; this one walks the long reads of the tile
+      const int rm = (tile << 6) + lane;
+      unsigned long long todo = __ballot(rm < n_reads && read_len[rm] > kLaneReadMax);
+      for (; todo; todo &= todo - 1) {
+        const int r = (tile << 6) + __ffsll((long long)todo) - 1;
         const uint8_t fl = rflags[r];
         const int L = read_len[r];
         int st = 0;
@@ -585,6 +591,7 @@ __global__ __launch_bounds__(256) void restore_bases_kernel(int32_t n_reads, con
             }
         }
         if (lane == 0) status[r] = st;
+      }
     }
 }
 
@@ -594,7 +601,13 @@ __global__ __launch_bounds__(256) void restore_quals_kernel(int32_t n_reads, con
                                                             const int64_t* out_off, int32_t* status) {
     const int lane = threadIdx.x & 63;
     const int n_waves = wave_count();
-    for (int r = wave_index(); r < n_reads; r += n_waves) {
+    const int n_tiles = (n_reads + 63) >> 6;
+    for (int tile = wave_index(); tile < n_tiles; tile += n_waves) {
+      // short reads belong to the lane-per-read kernel; this one walks the long reads of the tile
+      const int rm = (tile << 6) + lane;
+      unsigned long long todo = __ballot(rm < n_reads && read_len[rm] > kLaneReadMax);
+      for (; todo; todo &= todo - 1) {
+        const int r = (tile << 6) + __ffsll((long long)todo) - 1;
         const uint8_t fl = rflags[r];
         const int L = read_len[r];
         int st;
@@ -631,6 +644,204 @@ __global__ __launch_bounds__(256) void restore_quals_kernel(int32_t n_reads, con
             }
         }
         if (lane == 0) status[r] = st;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// N1 / N2 for short reads (max read length <= kLaneReadMax): one LANE per read, 16 bases per step, the same
+// statements as restore_bases_kernel / restore_quals_kernel above (which stay in charge of long reads).
+// ------------------------------------------------------------------------------------------------------
+// dst[0..cnt) = normalizeBase(window[rp + i]), 'N' at and beyond the window's end (getByteOrDefault :436-441).
+// room = bytes of the read from dst on: a whole 16-byte unit is stored only inside the read.
+__device__ __forceinline__ void copy_ref_norm(uint8_t* dst, const uint8_t* win, int64_t rp, int cnt, int64_t wlen, int room) {
+    int i = 0;
+    for (; i + 16 <= cnt && rp + i + 16 <= wlen; i += 16) {
+        PackedU32x4 t = *reinterpret_cast<const PackedU32x4*>(win + rp + i);
+#pragma unroll
+        for (int c = 0; c < 4; c++) t.v[c] = normalize4(t.v[c]);
+        *reinterpret_cast<PackedU32x4*>(dst + i) = t;
+    }
+    (void)room;
+    for (; i < cnt; i++) dst[i] = normalize_base(rp + i >= wlen ? (uint8_t)'N' : win[rp + i]);
+}
+
+__global__ __launch_bounds__(256) void restore_bases_lane_kernel(int32_t n_reads, const int32_t* read_len,
+                                                                 const int32_t* aln_start, const uint8_t* rflags,
+                                                                 const int32_t* read_cont, const cramgpu_refwin* wins,
+                                                                 cramgpu_features F, const uint8_t* seq,
+                                                                 const int64_t* seq_off, const uint8_t* ref,
+                                                                 const uint8_t* basesof, uint8_t* out,
+                                                                 const int64_t* out_off, int32_t* status) {
+    const int stride = (int)(gridDim.x * blockDim.x);
+    for (int r = (int)(blockIdx.x * blockDim.x + threadIdx.x); r < n_reads; r += stride) {
+        const uint8_t fl = rflags[r];
+        const int L = read_len[r];
+        if (L > kLaneReadMax) continue;  // restore_bases_kernel
+        int st = 0;
+        if (fl & CRAMGPU_RF_SKIP) {
+            st = 2;
+        } else if ((fl & CRAMGPU_RF_UNKNOWN_BASES) || L == 0) {
+            st = 1;  // :336-337 NULL_SEQUENCE
+        } else {
+            const int cont = read_cont ? read_cont[r] : 0;
+            const cramgpu_refwin W = wins[cont];
+            const uint8_t* win = ref + W.ref_off;
+            const int64_t wlen = W.ref_len, ws0 = W.ref_start0;
+            const uint8_t* bo = basesof + (size_t)cont * 20;
+            uint8_t* b = out + out_off[r];
+            const int64_t al0 = (int64_t)aln_start[r] - 1;
+            const int64_t fb = F.off[r], fe = F.off[r + 1];
+            if (fb == fe) {
+                // :343-364 no features: plain copy, 'N' beyond the window, no normalisation
+                if (wlen + ws0 < al0 + L) {
+                    const int64_t off = al0 - ws0, avail = wlen - off;
+                    const int64_t ncopy = (off > 0 && avail > 0) ? (L < avail ? L : avail) : 0;
+                    for (int i = 0; i < L; i++) b[i] = i < ncopy ? win[off + i] : (uint8_t)'N';
+                } else if (al0 - ws0 < 0) {
+                    st = CRAMGPU_E_JAVA_THROWS;
+                } else {
+                    const uint8_t* s = win + (al0 - ws0);
+                    int i = 0;
+                    for (; i + 16 <= L; i += 16)
+                        *reinterpret_cast<PackedU32x4*>(b + i) = *reinterpret_cast<const PackedU32x4*>(s + i);
+                    for (; i < L; i++) b[i] = s[i];
+                }
+            } else {
+                int pir = 1;      // posInRead (1-based)
+                int64_t pis = 0;  // posInSeq
+                bool bad = false;
+                for (int64_t f = fb; f < fe && !bad; f++) {
+                    const int fpos = F.pos[f];
+                    const int opc = F.op[f];
+                    const int32_t fa = F.a[f], fbv = F.b[f];
+                    const int gap = fpos - pir;
+                    if (gap > 0) {  // :368-370 copy reference up to the feature
+                        if (al0 + pis - ws0 < 0 || pir - 1 + gap > L) {
+                            bad = true;
+                            break;
+                        }
+                        copy_ref_norm(b + pir - 1, win, al0 + pis - ws0, gap, wlen, L - (pir - 1));
+                        pir += gap;
+                        pis += gap;
+                    }
+                    if (opc == 'X') {
+                        const int64_t rp = al0 + pis - ws0;
+                        if (rp < 0 || pir - 1 >= L) {
+                            bad = true;
+                            break;
+                        }
+                        const uint8_t rbase = normalize_base(rp >= wlen ? (uint8_t)'N' : win[rp]);
+                        b[pir - 1] = normalize_base(bo[acgtn_index(rbase) * 4 + ((fa >> 16) & 3)]);
+                        pir++;
+                        pis++;
+                    } else if (opc == 'I' || opc == 'S') {
+                        if (fbv < 0 || pir - 1 + fbv > L) {
+                            bad = true;
+                            break;
+                        }
+                        const uint8_t* s = seq + seq_off[r] + fa;
+                        for (int i = 0; i < fbv; i++) b[pir - 1 + i] = normalize_base(s[i]);
+                        pir += fbv;
+                    } else if (opc == 'D' || opc == 'N') {
+                        pis += fa;
+                    } else if (opc == 'i') {
+                        if (pir - 1 >= L) {
+                            bad = true;
+                            break;
+                        }
+                        b[pir - 1] = normalize_base((uint8_t)fa);
+                        pir++;
+                    }
+                }
+                if (!bad) {
+                    // :412-415 tail from the reference while it lasts, then the never-written rest reads as 0 -> 'N'
+                    const int64_t rp0 = al0 + pis - ws0;
+                    const int rest = L - (pir - 1);
+                    int64_t ncopy = rest;
+                    if (wlen - rp0 < ncopy) ncopy = wlen - rp0;
+                    if (ncopy < 0) ncopy = 0;
+                    if (ncopy > 0 && rp0 < 0) {
+                        bad = true;
+                    } else {
+                        if (ncopy > 0) copy_ref_norm(b + pir - 1, win, rp0, (int)ncopy, wlen, rest);
+                        for (int i = (int)ncopy; i < rest; i++) b[pir - 1 + i] = (uint8_t)'N';
+                        // :418-427 ReadBase features overwrite
+                        for (int64_t f = fb; f < fe; f++) {
+                            if (F.op[f] == 'B') {
+                                const int p = F.pos[f];
+                                if (p < 1 || p > L)
+                                    bad = true;
+                                else
+                                    b[p - 1] = normalize_base((uint8_t)F.a[f]);
+                            }
+                        }
+                    }
+                }
+                if (bad) st = CRAMGPU_E_JAVA_THROWS;
+            }
+        }
+        status[r] = st;
+    }
+}
+
+__global__ __launch_bounds__(256) void restore_quals_lane_kernel(int32_t n_reads, const int32_t* read_len,
+                                                                 const uint8_t* rflags, cramgpu_features F,
+                                                                 uint8_t default_qs, uint8_t* scores,
+                                                                 const int64_t* out_off, int32_t* status) {
+    const int stride = (int)(gridDim.x * blockDim.x);
+    const uint32_t dq4 = default_qs * 0x01010101u;
+    for (int r = (int)(blockIdx.x * blockDim.x + threadIdx.x); r < n_reads; r += stride) {
+        const uint8_t fl = rflags[r];
+        const int L = read_len[r];
+        if (L > kLaneReadMax) continue;  // restore_quals_kernel
+        int st;
+        if (fl & CRAMGPU_RF_SKIP) {
+            st = 2;
+        } else {
+            uint8_t* s = scores + out_off[r];
+            if (!(fl & CRAMGPU_RF_FORCE_QS)) {
+                int i = 0;
+                for (; i + 16 <= L; i += 16) *reinterpret_cast<PackedU32x4*>(s + i) = PackedU32x4{{dq4, dq4, dq4, dq4}};
+                for (; i < L; i++) s[i] = default_qs;
+                bool any = false;
+                for (int64_t f = F.off[r]; f < F.off[r + 1]; f++) {
+                    const int opc = F.op[f];
+                    if (opc == 'Q') {
+                        s[F.pos[f] - 1] = (uint8_t)F.a[f];
+                        any = true;
+                    } else if (opc == 'B') {
+                        s[F.pos[f] - 1] = (uint8_t)F.b[f];
+                        any = true;
+                    }
+                }
+                st = any ? 0 : 1;
+            } else {
+                int missing = 0, i = 0;
+                for (; i + 16 <= L; i += 16) {
+                    const PackedU32x4 t = *reinterpret_cast<const PackedU32x4*>(s + i);
+                    uint32_t all = 0x80808080u;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {  // high bit of a byte stays set iff the byte is not 0xFF
+                        const uint32_t inv = ~t.v[c];
+                        all &= ((inv & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | inv;
+                    }
+                    if ((all & 0x80808080u) == 0x80808080u) continue;
+                    for (int j = 0; j < 16; j++)
+                        if (s[i + j] == 0xFF) {
+                            s[i + j] = default_qs;
+                            missing++;
+                        }
+                }
+                for (; i < L; i++)
+                    if (s[i] == 0xFF) {
+                        s[i] = default_qs;
+                        missing++;
+                    }
+                st = missing == L ? 1 : 0;
+            }
+        }
+        status[r] = st;
     }
 }
 
@@ -857,6 +1068,10 @@ __global__ void merge_quality_kernel(int32_t n_reads, const int32_t* read_len, c
 
 }  // namespace
 
+static int lane_grid(int64_t n_reads) {  // a lane per read, grid-stride beyond 8192 workgroups
+    const int64_t blocks = (n_reads + 255) / 256;
+    return (int)(blocks < 1 ? 1 : blocks > 256 * 32 ? 256 * 32 : blocks);
+}
 static int grid_for_waves(int64_t n_items, int waves_per_block) {
     int64_t blocks = (n_items + waves_per_block - 1) / waves_per_block;
     if (blocks < 1) blocks = 1;
@@ -867,8 +1082,7 @@ static int grid_for_waves(int64_t n_items, int waves_per_block) {
 hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
                                    int32_t* d_counts, bool write_pass, hipStream_t s) {
     if (r.max_read_len <= kLaneReadMax) {  // short reads: a lane per read
-        int64_t blocks = ((int64_t)r.n_reads + 255) / 256;
-        const int grid = (int)(blocks < 1 ? 1 : blocks > 256 * 32 ? 256 * 32 : blocks);
+        const int grid = lane_grid(r.n_reads);
         if (write_pass)
             hipLaunchKernelGGL(extract_lane_kernel<true>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts);
         else
@@ -918,7 +1132,10 @@ hipError_t launch_restore_bases(int32_t n_reads, const int32_t* read_len, const 
                                 const int32_t* read_cont, const cramgpu_refwin* wins, cramgpu_features f,
                                 const uint8_t* seq, const int64_t* seq_off, const uint8_t* ref, const uint8_t* d_basesof,
                                 uint8_t* out, const int64_t* out_off, int32_t* status, hipStream_t s) {
-    hipLaunchKernelGGL(restore_bases_kernel, dim3(grid_for_waves(n_reads, 4)), dim3(256), 0, s, n_reads, read_len,
+    // reads up to kLaneReadMax bases: a lane each; longer ones: a wave each (found 64 reads at a time)
+    hipLaunchKernelGGL(restore_bases_lane_kernel, dim3(lane_grid(n_reads)), dim3(256), 0, s, n_reads, read_len, aln_start,
+                       rflags, read_cont, wins, f, seq, seq_off, ref, d_basesof, out, out_off, status);
+    hipLaunchKernelGGL(restore_bases_kernel, dim3(grid_for_waves(((int64_t)n_reads + 63) / 64, 4)), dim3(256), 0, s, n_reads, read_len,
                        aln_start, rflags, read_cont, wins, f, seq, seq_off, ref, d_basesof, out, out_off, status);
     return hipGetLastError();
 }
@@ -926,7 +1143,9 @@ hipError_t launch_restore_bases(int32_t n_reads, const int32_t* read_len, const 
 hipError_t launch_restore_quals(int32_t n_reads, const int32_t* read_len, const uint8_t* rflags, cramgpu_features f,
                                 uint8_t default_qs, uint8_t* scores, const int64_t* out_off, int32_t* status,
                                 hipStream_t s) {
-    hipLaunchKernelGGL(restore_quals_kernel, dim3(grid_for_waves(n_reads, 4)), dim3(256), 0, s, n_reads, read_len, rflags,
+    hipLaunchKernelGGL(restore_quals_lane_kernel, dim3(lane_grid(n_reads)), dim3(256), 0, s, n_reads, read_len, rflags,
+                       f, default_qs, scores, out_off, status);
+    hipLaunchKernelGGL(restore_quals_kernel, dim3(grid_for_waves(((int64_t)n_reads + 63) / 64, 4)), dim3(256), 0, s, n_reads, read_len, rflags,
                        f, default_qs, scores, out_off, status);
     return hipGetLastError();
 }
