@@ -14,6 +14,8 @@
 // reference window.  Mismatches are compacted with a wave ballot + mbcnt prefix so that features leave in the
 // reference's order (CIGAR order, ascending position).  Feature extraction runs twice (count, exclusive scan,
 // write) because the feature arrays are dense across reads.
+#include <cstdlib>
+
 #include "internal.h"
 
 namespace {
@@ -1068,9 +1070,14 @@ __global__ void merge_quality_kernel(int32_t n_reads, const int32_t* read_len, c
 
 }  // namespace
 
-static int lane_grid(int64_t n_reads) {  // a lane per read, grid-stride beyond 8192 workgroups
-    const int64_t blocks = (n_reads + 255) / 256;
-    return (int)(blocks < 1 ? 1 : blocks > 256 * 32 ? 256 * 32 : blocks);
+static int lane_grid(int64_t n_reads) {  // a lane per read, grid-stride beyond the resident workgroups
+    static const int per_cu = [] {
+        const char* e = getenv("CRAMGPU_LANE_WGS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 && v <= 64 ? v : 32;
+    }();
+    const int64_t blocks = (n_reads + 255) / 256, cap = 256 * (int64_t)per_cu;
+    return (int)(blocks < 1 ? 1 : blocks > cap ? cap : blocks);
 }
 static int grid_for_waves(int64_t n_items, int waves_per_block) {
     int64_t blocks = (n_items + waves_per_block - 1) / waves_per_block;

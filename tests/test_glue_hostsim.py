@@ -42,6 +42,8 @@ def test_rans_gpu_test_bodies(hostsim, kat1, orc):
         t.test_empty_short_and_errors(xc, orc)
         t.test_decoder_accepts_oracle_streams(eng, orc)
         t.test_corrupt_streams_do_not_crash(eng, orc)
+        import test_foreign_streams as tf
+        tf.check_library_decodes(xc)  # tables summing to 4096, F = 4096 in both spellings
         # device-arena entry points + gather, as bench.py drives them
         datas = [bytes([65 + (i * 7 + k) % 5 for i in range(300 + 17 * k)]) for k in range(6)]
         orders = [k & 1 for k in range(6)]
