@@ -339,10 +339,17 @@ __device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, int M_, con
                 pk |= (xa << 20) <= e[m] ? ((e[m] & ~4095u) | (xa & 4095u)) : 0u;
             }
         } else {
-            for (int m = 0; m < M; m++) {
-                const uint32_t em = rows[roff + 16 * m];
-                const uint32_t xa = x + em;
-                pk |= (xa << 20) <= em ? ((em & ~4095u) | (xa & 4095u)) : 0u;
+            // four entries per round trip (rows of wide alphabets live in global memory; eight at a time were slower);
+            // an index past the row's end repeats the last entry, which ORs to the same word
+            for (int m = 0; m < M; m += 4) {
+                uint32_t em[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) em[c] = rows[roff + 16 * (m + c < M ? m + c : M - 1)];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t xa = x + em[c];
+                    pk |= (xa << 20) <= em[c] ? ((em[c] & ~4095u) | (xa & 4095u)) : 0u;
+                }
             }
         }
         pk = row_or(pk);
@@ -415,6 +422,14 @@ __device__ void decode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* g
         } else if (raw == 0) {
             result = 0;
         } else {
+#ifndef HIP_SIM
+            // the launch lasts as long as its longest chains: a long block's wave issues ahead of the waves of
+            // short blocks that share its SIMD
+            if (raw >= (1 << 18))
+                __builtin_amdgcn_s_setprio(3);
+            else
+                __builtin_amdgcn_s_setprio(0);
+#endif
             Stream S{src, len, 0, L->ring, make_uint4(0, 0, 0, 0)};
             S.reset();
             int32_t p = 9;
