@@ -108,6 +108,7 @@ struct cramgpu_ctx {
     PinBuf<int64_t> h_off;
     // record kernels
     DevBuf<int32_t> d_counts;
+    DevBuf<int32_t> d_list;
     DevBuf<int64_t> d_total, d_scan_ws;
     PinBuf<int64_t> h_total;
     DevBuf<uint8_t> d_small;   // matrix tables, policies
@@ -281,7 +282,7 @@ void cramgpu_close(cramgpu_ctx* c) {
     c->h_desc.release(); c->h_perm.release(); c->d_desc.release(); c->d_perm.release();
     c->d_in.release(); c->d_out.release(); c->d_pack.release(); c->d_len.release(); c->d_pos.release();
     c->d_off.release(); c->d_err.release(); c->h_stage.release(); c->h_len.release(); c->h_off.release();
-    c->d_counts.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_small.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
+    c->d_counts.release(); c->d_list.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_small.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
     if (c->staged) (void)hipEventDestroy(c->staged);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -482,14 +483,18 @@ int64_t cramgpu_extract_features_dev(cramgpu_ctx* c, const cramgpu_reads* reads,
     hipStream_t s = pick(c, stream);
     const int32_t n = reads->n_reads;
     HIPCHK(c->d_counts.reserve((size_t)n + 1));
-    if (n > 0) HIPCHK(launch_extract_features(*reads, d_ref, *feats, nullptr, c->d_counts.p, false, s));
+    HIPCHK(c->d_list.reserve((size_t)n + 1));  // reads that have features + (last word) their number
+    int32_t* list = c->d_list.p;
+    uint32_t* list_n = reinterpret_cast<uint32_t*>(c->d_list.p + n);
+    if (n > 0) HIPCHK(launch_extract_features(*reads, d_ref, *feats, nullptr, c->d_counts.p, false, list, list_n, s));
     HIPCHK(c->d_scan_ws.reserve(feature_scan_ws_elems(n)));
     HIPCHK(launch_feature_scan(n, c->d_counts.p, feats->off, c->d_total.p, c->d_scan_ws.p, s));
     HIPCHK(hipMemcpyAsync(c->h_total.p, c->d_total.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const int64_t total = c->h_total.p[0];
     if (total > feats->cap) return fail(CRAMGPU_E_INSUFFICIENT, "extract_features: feature capacity too small");
-    if (n > 0 && total > 0) HIPCHK(launch_extract_features(*reads, d_ref, *feats, d_sub_hist, c->d_counts.p, true, s));
+    if (n > 0 && total > 0)
+        HIPCHK(launch_extract_features(*reads, d_ref, *feats, d_sub_hist, c->d_counts.p, true, list, list_n, s));
     return total;
 }
 

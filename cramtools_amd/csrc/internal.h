@@ -57,7 +57,7 @@ hipError_t launch_gather(const uint8_t* src, const int64_t* pos, const int32_t* 
 
 // record kernels
 hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
-                                   int32_t* d_counts, bool write_pass, hipStream_t s);
+                                   int32_t* d_counts, bool write_pass, int32_t* list, uint32_t* list_n, hipStream_t s);
 size_t feature_scan_ws_elems(int32_t n_reads);  // int64 elements of workspace launch_feature_scan needs
 hipError_t launch_feature_scan(int32_t n_reads, const int32_t* d_counts, int64_t* d_off, int64_t* d_total, int64_t* d_ws,
                                hipStream_t s);

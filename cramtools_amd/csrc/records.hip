@@ -225,11 +225,11 @@ __device__ __forceinline__ uint32_t normalize4(uint32_t x) {
     return (y & ~m) | (0x4E4E4E4Eu & m);
 }
 
+// the features of read r (WRITE: emitted at F.off[r]); returns their number
 template <bool WRITE>
-__global__ __launch_bounds__(256) void extract_lane_kernel(cramgpu_reads R, const uint8_t* ref, cramgpu_features F,
-                                                           int64_t* sub_hist, int32_t* counts) {
-    const int stride = (int)(gridDim.x * blockDim.x);
-    for (int r = (int)(blockIdx.x * blockDim.x + threadIdx.x); r < R.n_reads; r += stride) {
+__device__ __forceinline__ int64_t lane_read_features(const cramgpu_reads& R, const uint8_t* ref, const cramgpu_features& F,
+                                                      int64_t* sub_hist, int r) {
+    {
         const int32_t fl = R.rflags[r];
         const int32_t start = R.aln_start[r];
         const bool mapped = !(fl & (CRAMGPU_RF_UNMAPPED | CRAMGPU_RF_SKIP)) && start != 0;
@@ -326,8 +326,60 @@ __global__ __launch_bounds__(256) void extract_lane_kernel(cramgpu_reads R, cons
                 if (consumes_ref(op)) refoff += len;
             }
         }
-        if (!WRITE) counts[r] = (int32_t)nf;
+        return nf;
     }
+}
+
+// Count pass: counts[r] for every read, and the reads that have features collected in `list` (any order: every read
+// writes at its own offset), so that the write pass spends its lanes only on those (14 % of Illumina-like reads).
+__global__ __launch_bounds__(256) void extract_lane_count_kernel(cramgpu_reads R, const uint8_t* ref, cramgpu_features F,
+                                                                 int32_t* counts, int32_t* list, uint32_t* list_n) {
+    // the workgroup collects its reads in LDS and claims list space with one global atomic per flush (156 000 wave
+    // atomics on one address cost 0.7 ms: the L2 serialises them)
+    constexpr uint32_t kCap = 2048;
+    __shared__ int32_t sl[kCap];
+    __shared__ uint32_t sn, sbase;
+    const int stride = (int)(gridDim.x * blockDim.x);
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) sn = 0;
+    __syncthreads();
+    auto flush = [&]() {  // called by the whole workgroup
+        if (threadIdx.x == 0) sbase = sn ? atomicAdd(list_n, sn) : 0u;
+        __syncthreads();
+        const uint32_t cnt = sn, base = sbase;
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) list[base + i] = sl[i];
+        __syncthreads();
+        if (threadIdx.x == 0) sn = 0;
+        __syncthreads();
+    };
+    for (int r0 = (int)(blockIdx.x * blockDim.x); r0 < R.n_reads; r0 += stride) {  // uniform per workgroup
+        const int r = r0 + (int)threadIdx.x;
+        int64_t nf = 0;
+        if (r < R.n_reads) {
+            nf = lane_read_features<false>(R, ref, F, nullptr, r);
+            counts[r] = (int32_t)nf;
+        }
+        const unsigned long long m = __ballot(nf > 0);
+        if (m != 0) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&sn, (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (nf > 0) sl[base + mbcnt(m)] = r;
+        }
+        __syncthreads();
+        if (sn > kCap - 256) flush();
+    }
+    flush();
+}
+
+__global__ __launch_bounds__(256) void extract_lane_write_kernel(cramgpu_reads R, const uint8_t* ref, cramgpu_features F,
+                                                                 int64_t* sub_hist, const int32_t* list,
+                                                                 const uint32_t* list_n) {
+    const uint32_t n = *list_n;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        lane_read_features<true>(R, ref, F, sub_hist, list[i]);
 }
 
 // Exclusive scan of int32 counts into int64 offsets (off[n] = total) in three launches: per-tile sums, scan of the
@@ -1087,13 +1139,18 @@ static int grid_for_waves(int64_t n_items, int waves_per_block) {
 }
 
 hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
-                                   int32_t* d_counts, bool write_pass, hipStream_t s) {
-    if (r.max_read_len <= kLaneReadMax) {  // short reads: a lane per read
-        const int grid = lane_grid(r.n_reads);
-        if (write_pass)
-            hipLaunchKernelGGL(extract_lane_kernel<true>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts);
-        else
-            hipLaunchKernelGGL(extract_lane_kernel<false>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts);
+                                   int32_t* d_counts, bool write_pass, int32_t* list, uint32_t* list_n, hipStream_t s) {
+    if (r.max_read_len <= kLaneReadMax && list && list_n) {  // short reads: a lane per read
+        if (write_pass) {
+            // the list holds the reads with features: at most n_reads, usually a small fraction
+            hipLaunchKernelGGL(extract_lane_write_kernel, dim3(lane_grid(((int64_t)r.n_reads + 3) / 4)), dim3(256), 0, s, r,
+                               ref, f, sub_hist, list, list_n);
+        } else {
+            hipError_t e = hipMemsetAsync(list_n, 0, sizeof(uint32_t), s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(extract_lane_count_kernel, dim3(lane_grid(r.n_reads)), dim3(256), 0, s, r, ref, f, d_counts,
+                               list, list_n);
+        }
         return hipGetLastError();
     }
     const int grid = grid_for_waves(((int64_t)r.n_reads + 63) / 64, 4);  // a wave per tile of 64 reads

@@ -1,8 +1,9 @@
 #!/bin/bash
-mkdir -p gpurun_out
 set -o pipefail
-for W in 2 4 8 16 32; do
-  echo "== CRAMGPU_LANE_WGS_PER_CU=$W"
-  CRAMGPU_LANE_WGS_PER_CU=$W timeout -k 10 200 python3 -u scripts/k3_time.py > gpurun_out/k3_w$W.log 2>&1 || { echo "k3_time failed"; tail -30 gpurun_out/k3_w$W.log; exit 1; }
-  tail -4 gpurun_out/k3_w$W.log
-done
+R=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/prof_k3
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_k3 -o k3 --output-format csv -- python3 -u $R/scripts/k3_time.py > $R/gpurun_out/k3.log 2>&1 || { echo "failed"; tail -30 $R/gpurun_out/k3.log; exit 1; }
+find $R/gpurun_out/prof_k3 -name "*kernel_stats*" | head -2
+grep "extract\|scan_\|restore\|matrices\|assign" $(find $R/gpurun_out/prof_k3 -name "*kernel_stats.csv" | head -1) | cut -c1-200
