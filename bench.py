@@ -359,7 +359,7 @@ def main():
 
     # decode leg (configs[2]) on rank 0, outside the timed region of the headline metric
     dec, dec_parity = None, None
-    if rank == 0 and not a.no_decode:
+    if rank == 0 and not a.no_decode and world == 1:
         dec = DecodeStep(dev, eng, w, step)
         dec.prepare()
         for _ in range(1 + a.steps):
@@ -373,7 +373,7 @@ def main():
     comp_bytes = int(lens[lens > 0].sum())
     extra = {}
     if rank == 0:
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # the CPU leg and its block-by-block parity run at N = 1 only
             base, (out, ooff, olen, n_c) = cpu_baseline(w)
             extra["cpu_baseline"] = base
             ns = len(SERIES)

@@ -845,15 +845,47 @@ __global__ __launch_bounds__(256) void restore_quals_lane_kernel(int32_t n_reads
                                                                  const int64_t* out_off, int32_t* status) {
     const int stride = (int)(gridDim.x * blockDim.x);
     const uint32_t dq4 = default_qs * 0x01010101u;
-    for (int r = (int)(blockIdx.x * blockDim.x + threadIdx.x); r < n_reads; r += stride) {
-        const uint8_t fl = rflags[r];
-        const int L = read_len[r];
-        if (L > kLaneReadMax) continue;  // restore_quals_kernel
+    const int lane = threadIdx.x & 63;
+    for (int r0 = (int)(blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); r0 < n_reads; r0 += stride) {  // uniform per wave
+        const int r = r0 + lane;
+        const bool valid = r < n_reads;
+        const uint8_t fl = valid ? rflags[r] : (uint8_t)CRAMGPU_RF_SKIP;
+        const int L = valid ? read_len[r] : 0;
+        const int64_t off = valid ? out_off[r] : 0;
+        // Usual case of a lossless container: 64 force-preserved reads whose score arrays lie back to back.  The wave
+        // then scans the whole span with coalesced 16-byte loads (a lane walking its own read at a 150-byte stride
+        // fetches every line four times) and falls back to the per-read code only if it meets a 0xFF hole.
+        {
+            const int64_t nxt = __shfl(off, (lane + 1) & 63);
+            const bool plain = valid && (fl & (CRAMGPU_RF_SKIP | CRAMGPU_RF_FORCE_QS)) == CRAMGPU_RF_FORCE_QS && L > 0 &&
+                               L <= kLaneReadMax && (lane == 63 || nxt == off + L);
+            if (__ballot(plain) == ~0ull) {
+                const int64_t lo = __shfl(off, 0), hi = __shfl(off + L, 63);
+                bool hole = false;
+                int64_t p = lo + lane * 16;
+                for (; p + 16 <= hi; p += 1024) {
+                    const PackedU32x4 t = *reinterpret_cast<const PackedU32x4*>(scores + p);
+                    uint32_t all = 0x80808080u;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const uint32_t inv = ~t.v[c];
+                        all &= ((inv & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | inv;
+                    }
+                    hole |= (all & 0x80808080u) != 0x80808080u;
+                }
+                for (; p < hi; p++) hole |= scores[p] == 0xFF;  // the lane that owns the last, partial unit
+                if (__ballot(hole) == 0) {
+                    status[r] = 0;
+                    continue;
+                }
+            }
+        }
+        if (!valid || L > kLaneReadMax) continue;  // long reads: restore_quals_kernel
         int st;
         if (fl & CRAMGPU_RF_SKIP) {
             st = 2;
         } else {
-            uint8_t* s = scores + out_off[r];
+            uint8_t* s = scores + off;
             if (!(fl & CRAMGPU_RF_FORCE_QS)) {
                 int i = 0;
                 for (; i + 16 <= L; i += 16) *reinterpret_cast<PackedU32x4*>(s + i) = PackedU32x4{{dq4, dq4, dq4, dq4}};

@@ -104,6 +104,7 @@ def test_records_gpu_random_bodies(hostsim, orc, monkeypatch):
         rk = (records, eng)
         t.test_random_containers_vs_oracle(rk, orc, False)
         t.test_multi_container_batch(rk, orc)
+        t.test_restore_quals_many_reads(rk, orc)
     finally:
         eng.close()
 

@@ -302,3 +302,35 @@ def test_many_reads_offsets(rk, orc):
     for key in ("off", "op", "pos", "a"):
         assert np.array_equal(got[key], want[key]), key
     assert np.array_equal(hist[0], want["hist"])
+
+
+def test_restore_quals_many_reads(rk, orc):
+    """restoreQualityScores over a few hundred reads: back-to-back force-preserved arrays (the wave's coalesced span
+    scan), holes of -1 inside some of them, one array that is all holes (NULL_QUALS), a non-forced read with Q features
+    in the middle of the run, and a tail of fewer than 64 reads."""
+    records, eng = rk
+    rng = np.random.default_rng(33)
+    n = 64 * 5 + 23
+    lens = rng.integers(100, 152, n).astype(np.int32)
+    lens[:128] = 150
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    scores = rng.integers(2, 42, int(lens.sum()), dtype=np.uint8)
+    rflags = np.full(n, 16, np.uint8)  # CRAMGPU_RF_FORCE_QS
+    for r in (70, 71, 130, 200, 330):
+        k = rng.integers(0, lens[r], 5)
+        scores[off[r] + k] = 0xFF
+    scores[off[131]:off[131] + lens[131]] = 0xFF
+    rflags[260] = 0  # not forced: default + Q features
+    f_off = np.zeros(n + 1, np.int64)
+    f_off[261:] = 2
+    feats = dict(op=np.array([ord("Q"), ord("Q")], np.uint8), pos=np.array([3, 7], np.int32), a=np.array([11, 12], np.int32),
+                 b=np.zeros(2, np.int32), off=f_off)
+    want, wst = orc.restore_quals(lens, rflags, feats, scores)
+    fb = records.FeatureBatch.from_host(DEV, feats["op"], feats["pos"], feats["a"], feats["b"], feats["off"])
+    norm = records.CramNormalizer(eng)
+    got, st = norm.restore_quality_scores(DEV, lens, rflags, fb, np.concatenate([scores, np.zeros(16, np.uint8)]))
+    assert np.array_equal(st.cpu().numpy(), wst)
+    g = got.cpu().numpy()[:scores.size]
+    for r in range(n):
+        if wst[r] == 0:
+            assert np.array_equal(g[off[r]:off[r] + lens[r]], want[off[r]:off[r] + lens[r]]), r
