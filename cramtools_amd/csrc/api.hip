@@ -255,7 +255,11 @@ cramgpu_ctx* cramgpu_open(int32_t device_index) {
     c->prof_on = env_int("CRAMGPU_PROF", 0) != 0;
     // ask for a full share of the CU's LDS so that the dispatcher cannot stack more than dec_wpc decoder waves on one
     // CU while others hold fewer: the launch lasts as long as its slowest (most crowded) chain
-    if (env_int("CRAMGPU_DEC_LDS_SHARE", 1)) c->dec_lds = std::max(c->dec_lds, (size_t)(lds_per_cu / c->dec_wpc - 1024) & ~(size_t)255);
+    if (env_int("CRAMGPU_DEC_LDS_SHARE", 1)) {
+        c->dec_lds = std::max(c->dec_lds, (size_t)(lds_per_cu / c->dec_wpc - 1024) & ~(size_t)255);
+        // the share is there anyway: the table region takes all of it (ragged order-1 rows of wide alphabets)
+        c->dec_tab_bytes = (int)((c->dec_lds - rans_decode_fixed_lds()) & ~(size_t)15);
+    }
     c->n_waves_enc = c->n_cu * c->enc_wpc;
     c->n_waves_dec = c->n_cu * c->dec_wpc;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&

@@ -31,6 +31,8 @@ struct DecFixedLds {
     uint8_t dmap[256];
     uint8_t syml[256];
     uint8_t present[256];
+    uint16_t nsym[256];      // symbols listed by context (byte) i
+    uint32_t rowinfo[256];   // ragged rows: entry offset | 16-entry units << 24, by dense context
 };
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
@@ -226,8 +228,42 @@ struct FillO0 {
 };
 struct MarkO1 {
     uint8_t* present;
-    __device__ __forceinline__ void ctx(int i) { present[i] = 1; }
-    __device__ __forceinline__ void sym(int j, int, int) { present[j] = 1; }
+    uint16_t* nsym;
+    int cur;
+    __device__ __forceinline__ void ctx(int i) {
+        present[i] = 1;
+        cur = i;
+    }
+    __device__ __forceinline__ void sym(int j, int, int) {
+        present[j] = 1;
+        if (lane_id() == 0 && nsym[cur] < 256) nsym[cur]++;
+    }
+};
+// Ragged rows for wide alphabets: a context's row lists only the symbols it has, padded to a multiple of 16 with
+// copies of its first entry (a 200-symbol ITF8 series has ~3 symbols in most contexts: 13 tests per step become 1-2,
+// and the rows fit LDS).
+struct FillRagged {
+    uint32_t* rows;
+    const uint8_t* dmap;
+    const uint32_t* rowinfo;
+    uint32_t cur, cap, fill, first;
+    __device__ __forceinline__ void finish() {
+        if (fill > 0)
+            for (uint32_t q = fill + (uint32_t)lane_id(); q < cap; q += 64) rows[cur + q] = first;
+        fill = 0;
+    }
+    __device__ __forceinline__ void ctx(int i) {
+        finish();
+        const uint32_t info = rowinfo[dmap[i]];
+        cur = info & 0xFFFFFFu;
+        cap = 16u * (info >> 24);
+    }
+    __device__ __forceinline__ void sym(int j, int F, int C) {
+        const uint32_t e = ((4096u - (uint32_t)C) & 4095u) | ((uint32_t)dmap[j] << 12) | ((uint32_t)(F - 1) << 20);
+        if (fill == 0) first = e;
+        if (lane_id() == 0 && fill < cap) rows[cur + fill] = e;
+        fill++;
+    }
 };
 struct FillO1 {
     uint32_t* rows;  // [nd][stride]: (4096 - C) & 4095 | k << 12 | (F-1) << 20, see decode_o1
@@ -311,13 +347,14 @@ __device__ int decode_o0(Stream& S, int32_t p, const uint32_t* R, uint8_t* out, 
 // so that with xa = x + entry the slot offset inside the symbol is xa & 4095 and the slot belongs to the symbol iff
 // (xa << 20) <= entry (C + F <= 4096 keeps a slot below C from aliasing).  Lane s of a state's row tests the symbols
 // s, s+16, ...; symbols a context does not have carry a copy of one it has, so every hit ORs to the same word.
-template <int MS>  // MS > 0: M known at compile time (the next row is fetched while the state is renormalised)
-__device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, int M_, const uint8_t* syml, uint8_t* out,
-                         int32_t n) {
+// MS > 0: square rows[nd][16*MS], MS known at compile time (the next row is fetched while the state renormalises).
+// MS == 0: ragged rows (FillRagged): rowinfo[k] = entry offset | 16-entry units << 24 of context k's row.
+template <int MS>
+__device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, const uint32_t* rowinfo, const uint8_t* syml,
+                         uint8_t* out, int32_t n) {
     const int l = lane_id();
     const int g = l >> 4, s = l & 15;
-    const int M = MS > 0 ? MS : M_;
-    const uint32_t stride = 16u * (uint32_t)M;
+    const uint32_t stride = 16u * (uint32_t)(MS > 0 ? MS : 1);
     if (p + 16 > S.len) return CRAMGPU_E_CORRUPT;
     const Payload P{uniform_ptr(S.src), UNIFORM(S.len)};
     uint32_t x = (uint32_t)P.window(p + 4 * g);
@@ -326,9 +363,14 @@ __device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, int M_, con
     const int32_t q = n >> 2;
     uint32_t e[MS > 0 ? MS : 1];
     uint32_t roff = (uint32_t)s;  // context 0
+    uint32_t Mc = 1;               // ragged: 16-entry units of this state's current row
     if (MS > 0) {
 #pragma unroll
         for (int m = 0; m < MS; m++) e[m] = rows[roff + 16 * m];
+    } else {
+        const uint32_t info = rowinfo[0];
+        roff = (info & 0xFFFFFFu) + (uint32_t)s;
+        Mc = info >> 24;
     }
     auto step = [&](bool live) -> uint32_t {
         uint32_t pk = 0;
@@ -339,12 +381,12 @@ __device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, int M_, con
                 pk |= (xa << 20) <= e[m] ? ((e[m] & ~4095u) | (xa & 4095u)) : 0u;
             }
         } else {
-            // four entries per round trip (rows of wide alphabets live in global memory; eight at a time were slower);
-            // an index past the row's end repeats the last entry, which ORs to the same word
-            for (int m = 0; m < M; m += 4) {
+            // up to the longest row of the four states, four entries per round trip; an index past a row's end
+            // repeats its last entry, which ORs to the same word
+            for (uint32_t m = 0; __ballot(m < Mc) != 0; m += 4) {
                 uint32_t em[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) em[c] = rows[roff + 16 * (m + c < M ? m + c : M - 1)];
+                for (uint32_t c = 0; c < 4; c++) em[c] = rows[roff + 16u * (m + c < Mc ? m + c : Mc - 1u)];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const uint32_t xa = x + em[c];
@@ -355,10 +397,14 @@ __device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, int M_, con
         pk = row_or(pk);
         const uint32_t k = (pk >> 12) & 255u;
         if (live) {
-            roff = k * stride + (uint32_t)s;
             if (MS > 0) {
+                roff = k * stride + (uint32_t)s;
 #pragma unroll
                 for (int m = 0; m < MS; m++) e[m] = rows[roff + 16 * m];
+            } else {
+                const uint32_t info = rowinfo[k];
+                roff = (info & 0xFFFFFFu) + (uint32_t)s;
+                Mc = info >> 24;
             }
             x = ((pk >> 20) + 1u) * (x >> 12) + (pk & 4095u);
         }
@@ -443,18 +489,24 @@ __device__ void decode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* g
                 __syncthreads();
                 if (!rc) rc = decode_o0(S, p, R, out, raw);
             } else {
-                for (int i = l; i < 256; i += 64) L->present[i] = i == 0;
+                for (int i = l; i < 256; i += 64) {
+                    L->present[i] = i == 0;
+                    L->nsym[i] = 0;
+                }
                 __syncthreads();
-                MarkO1 mk{L->present};
+                MarkO1 mk{L->present, L->nsym, 0};
                 int32_t p1 = p;
                 rc = read_rows_o1(S, p1, mk);
                 __syncthreads();
                 if (!rc) {
-                    // dense alphabet in byte order, byte 0 first
-                    int nd = 0;
+                    // dense alphabet in byte order, byte 0 first; ragged row geometry alongside
+                    int nd = 0, total = 0;
                     if (l == 0) {
                         for (int j = 0; j < 256; j++) {
                             if (L->present[j]) {
+                                const int units = L->nsym[j] ? (L->nsym[j] + 15) >> 4 : 1;
+                                L->rowinfo[nd] = (uint32_t)total | ((uint32_t)units << 24);
+                                total += 16 * units;
                                 L->dmap[j] = (uint8_t)nd;
                                 L->syml[nd] = (uint8_t)j;
                                 nd++;
@@ -464,40 +516,49 @@ __device__ void decode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* g
                         }
                     }
                     nd = __shfl(nd, 0);
-                    __syncthreads();
-                    const int M = (nd + 15) >> 4, stride = 16 * M;
-                    const bool in_lds = nd * stride * 4 <= a.tab_bytes;
-                    uint32_t* rows = in_lds ? reinterpret_cast<uint32_t*>(tab) : reinterpret_cast<uint32_t*>(gs);
-                    if (in_lds)
-                        rows_clear(reinterpret_cast<uint32_t*>(tab), nd * stride);
-                    else
-                        rows_clear(reinterpret_cast<uint32_t*>(gs), nd * stride);
-                    __threadfence();
+                    total = __shfl(total, 0);
                     __syncthreads();
                     S.reset();
-                    FillO1 v{rows, L->dmap, stride, 0};
-                    rc = read_rows_o1(S, p, v);
-                    __threadfence();
-                    __syncthreads();
-                    if (!rc) {
-                        if (in_lds) {
-                            uint32_t* r = reinterpret_cast<uint32_t*>(tab);
+                    if (nd <= 48) {  // square rows, 16 * M entries each, always in LDS (<= 9 KiB)
+                        const int M = (nd + 15) >> 4, stride = 16 * M;
+                        uint32_t* r = reinterpret_cast<uint32_t*>(tab);
+                        rows_clear(r, nd * stride);
+                        __syncthreads();
+                        FillO1 v{r, L->dmap, stride, 0};
+                        rc = read_rows_o1(S, p, v);
+                        __syncthreads();
+                        if (!rc) {
                             rows_fix(r, nd, stride);
                             __syncthreads();
                             if (M == 1)
-                                rc = decode_o1<1>(S, p, r, M, L->syml, out, raw);
+                                rc = decode_o1<1>(S, p, r, nullptr, L->syml, out, raw);
                             else if (M == 2)
-                                rc = decode_o1<2>(S, p, r, M, L->syml, out, raw);
-                            else if (M == 3)
-                                rc = decode_o1<3>(S, p, r, M, L->syml, out, raw);
+                                rc = decode_o1<2>(S, p, r, nullptr, L->syml, out, raw);
                             else
-                                rc = decode_o1<0>(S, p, r, M, L->syml, out, raw);
+                                rc = decode_o1<3>(S, p, r, nullptr, L->syml, out, raw);
+                        }
+                    } else {  // ragged rows, in LDS when they fit (total <= 256 * 256 entries = the global scratch)
+                        const bool in_lds = total * 4 <= a.tab_bytes;
+                        if (in_lds) {
+                            uint32_t* r = reinterpret_cast<uint32_t*>(tab);
+                            for (int i = l; i < total; i += 64) r[i] = 0;
+                            __syncthreads();
+                            FillRagged v{r, L->dmap, L->rowinfo, 0, 0, 0, 0};
+                            rc = read_rows_o1(S, p, v);
+                            v.finish();
+                            __syncthreads();
+                            if (!rc) rc = decode_o1<0>(S, p, r, L->rowinfo, L->syml, out, raw);
                         } else {
                             uint32_t* r = reinterpret_cast<uint32_t*>(gs);
-                            rows_fix(r, nd, stride);
+                            for (int i = l; i < total; i += 64) r[i] = 0;
                             __threadfence();
                             __syncthreads();
-                            rc = decode_o1<0>(S, p, r, M, L->syml, out, raw);
+                            FillRagged v{r, L->dmap, L->rowinfo, 0, 0, 0, 0};
+                            rc = read_rows_o1(S, p, v);
+                            v.finish();
+                            __threadfence();
+                            __syncthreads();
+                            if (!rc) rc = decode_o1<0>(S, p, r, L->rowinfo, L->syml, out, raw);
                         }
                     }
                 }

@@ -99,6 +99,24 @@ int main(int argc, char** argv) {
                 for (auto& b : d) b = (uint8_t)((rng() % a) * (a <= 8 ? 31 : 1) + (a == 1 ? 65 : 0));
                 datas.push_back(d);
             }
+        {   // ITF8-like series: a wide alphabet whose contexts have few successors each (ragged order-1 rows in LDS)
+            Bytes itf;
+            for (int i = 0; i < (quick ? 400 : 6000); i++) {
+                int v = 250 + (int)(rng() % 101);
+                if (rng() & 1) {
+                    itf.push_back((uint8_t)(0x80 | (v >> 8)));
+                    itf.push_back((uint8_t)v);
+                } else {
+                    uint32_t u = (uint32_t)(-v);
+                    itf.push_back((uint8_t)(0xF0 | (u >> 28)));
+                    itf.push_back((uint8_t)(u >> 20));
+                    itf.push_back((uint8_t)(u >> 12));
+                    itf.push_back((uint8_t)(u >> 4));
+                    itf.push_back((uint8_t)(u & 0x0F));
+                }
+            }
+            datas.push_back(itf);
+        }
         Bytes runs(3000);
         for (size_t i = 0; i < runs.size(); i++) runs[i] = (uint8_t)((i / 37) % 5 + 40);
         datas.push_back(runs);
