@@ -113,6 +113,15 @@ struct Payload {
     int32_t len;         // uniform
     // the 8 stream bytes at offset p, little endian; clamped so that a corrupt stream cannot walk out of the arena
     // (the arena has 16 bytes of padding behind the last stream)
+    __device__ __forceinline__ unsigned long long window_v(uint32_t p) const {  // p in a vector register
+        const uint32_t c = p < (uint32_t)len ? p : (uint32_t)len;
+#ifdef HIP_SIM
+        return reinterpret_cast<const PackedU64*>(src + c)->v;
+#else
+        typedef const __attribute__((address_space(1))) PackedU64* GPtr;
+        return ((GPtr)((unsigned long long)src + c))->v;
+#endif
+    }
     __device__ __forceinline__ unsigned long long window(int32_t p) const {
         const int32_t c = p < len ? p : len;
 #ifdef HIP_SIM
@@ -132,7 +141,28 @@ __device__ __forceinline__ const uint8_t* uniform_ptr(const uint8_t* p) {
 // Decoding#RansDecRenorm for the four states of a step, in the reference's order rans0..rans3 from one shared cursor
 // (D04#uncompress L60-63, D14#uncompress L50-53).  A state lives in a 16-lane row (same value in every lane);
 // `w` holds the 8 stream bytes at `cur`: a step consumes at most 2 bytes per state.
-__device__ __forceinline__ void renorm(uint32_t& x, int32_t& cur, unsigned long long& w, const Payload& P, bool live) {
+// byte c of the result = byte sel[c] (0..7) of {hi:lo}
+__device__ __forceinline__ uint32_t perm8(uint32_t hi, uint32_t lo, uint32_t sel) {
+#ifdef HIP_SIM
+    const unsigned long long pool = ((unsigned long long)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int c = 0; c < 4; c++) r |= (uint32_t)((pool >> (8 * ((sel >> (8 * c)) & 7))) & 255u) << (8 * c);
+    return r;
+#else
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#endif
+}
+// a value the compiler must keep in a vector register and may not assume uniform
+__device__ __forceinline__ uint32_t in_vgpr(uint32_t v) {
+#ifndef HIP_SIM
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+// `cur` is the cursor for the (uniform) bounds checks, `curv` its copy in a vector register: the window address is
+// then a 32-bit vector offset on the scalar stream base (two vector instructions instead of five scalar ones).
+__device__ __forceinline__ void renorm(uint32_t& x, int32_t& cur, uint32_t& curv, unsigned long long& w, const Payload& P,
+                                       bool live) {
     const bool n1 = live && x < RANS_BYTE_L;
     const unsigned long long b1 = __ballot(n1);
     if (b1 != 0) {  // uniform; most steps of a well-compressed block need no byte at all
@@ -141,17 +171,19 @@ __device__ __forceinline__ void renorm(uint32_t& x, int32_t& cur, unsigned long 
         const unsigned long long m1 = b1 & kTop;
         uint32_t a = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
         int32_t tot = __popcll(m1);
-        uint32_t sh = n1 ? 8u : 0u;
+        // x <- x with 0, 1 or 2 stream bytes shifted in: a byte permutation of {x : window word}
+        uint32_t sel = n1 ? 0x06050400u : 0x07060504u;
         if (b2 != 0) {  // some state needs a second byte (that takes a symbol of frequency < 16)
             const unsigned long long m2 = b2 & kTop;
             a = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, a));
             tot += __popcll(m2);
-            sh = n2 ? 16u : sh;
+            sel = n2 ? 0x05040001u : sel;
         }
-        const uint32_t t = __builtin_bswap32((uint32_t)(w >> (8u * a)));  // this state's first byte on top
-        x = (uint32_t)((((unsigned long long)x << 32) | t) << sh >> 32);
+        const uint32_t t = (uint32_t)(w >> (8u * a));  // this state's bytes, first one lowest
+        x = perm8(x, t, sel);
         cur += tot;
-        w = P.window(cur);
+        curv += (uint32_t)tot;
+        w = P.window_v(curv);
     }
 }
 
@@ -311,6 +343,7 @@ __device__ int decode_o0(Stream& S, int32_t p, const uint32_t* R, uint8_t* out, 
     const Payload P{uniform_ptr(S.src), UNIFORM(S.len)};
     uint32_t x = (uint32_t)P.window(p + 4 * g);
     int32_t cur = UNIFORM(p) + 16;
+    uint32_t curv = in_vgpr((uint32_t)cur);
     unsigned long long w = P.window(cur);
     const int32_t nsteps = n >> 2;
     int32_t i = 0;
@@ -322,7 +355,7 @@ __device__ int decode_o0(Stream& S, int32_t p, const uint32_t* R, uint8_t* out, 
             const uint32_t e = R[x & 4095u];
             keep = row_push(keep, e);
             x = (((e >> 8) & 4095u) + 1u) * (x >> 12) + (e >> 20);
-            renorm(x, cur, w, P, true);
+            renorm(x, cur, curv, w, P, true);
         }
         out[4 * (i + 15 - s) + g] = (uint8_t)keep;
     }
@@ -333,7 +366,7 @@ __device__ int decode_o0(Stream& S, int32_t p, const uint32_t* R, uint8_t* out, 
             const uint32_t e = R[x & 4095u];
             keep = s == j ? e : keep;
             x = (((e >> 8) & 4095u) + 1u) * (x >> 12) + (e >> 20);
-            renorm(x, cur, w, P, true);
+            renorm(x, cur, curv, w, P, true);
         }
         if (s < rem) out[4 * (i + s) + g] = (uint8_t)keep;
     }
@@ -359,6 +392,7 @@ __device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, const uint3
     const Payload P{uniform_ptr(S.src), UNIFORM(S.len)};
     uint32_t x = (uint32_t)P.window(p + 4 * g);
     int32_t cur = UNIFORM(p) + 16;
+    uint32_t curv = in_vgpr((uint32_t)cur);
     unsigned long long w = P.window(cur);
     const int32_t q = n >> 2;
     uint32_t e[MS > 0 ? MS : 1];
@@ -408,7 +442,7 @@ __device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, const uint3
             }
             x = ((pk >> 20) + 1u) * (x >> 12) + (pk & 4095u);
         }
-        renorm(x, cur, w, P, live);
+        renorm(x, cur, curv, w, P, live);
         return k;
     };
     int32_t i = 0;
