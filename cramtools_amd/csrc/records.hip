@@ -63,14 +63,16 @@ __device__ __forceinline__ int64_t lane_bcast(int64_t v, int k) {
 
 template <bool WRITE>
 __global__ __launch_bounds__(256) void extract_kernel(cramgpu_reads R, const uint8_t* ref, cramgpu_features F,
-                                                      int64_t* sub_hist, int32_t* counts) {
+                                                      int64_t* sub_hist, int32_t* counts, int tile_reads) {
+    // tile_reads = 64: the tiled walk described above; tile_reads = 1: a wave per read (long reads: a tile of 64
+    // ten-kilobase reads would keep one wave busy for 640 000 bases while most of the GPU idles)
     const int lane = threadIdx.x & 63;
     const int n_waves = wave_count();
-    const int n_tiles = (R.n_reads + 63) >> 6;
+    const int n_tiles = (R.n_reads + tile_reads - 1) / tile_reads;
     for (int tile = wave_index(); tile < n_tiles; tile += n_waves) {
-        const int r0 = tile << 6;
+        const int r0 = tile * tile_reads;
         const int rm = r0 + lane;
-        const bool valid = rm < R.n_reads;
+        const bool valid = lane < tile_reads && rm < R.n_reads;
         // one read's metadata per lane
         int32_t m_fl = CRAMGPU_RF_SKIP, m_start = 0, m_nc = 0, m_cont = 0;
         int64_t m_boff = 0, m_coff = 0, m_off = 0;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void extract_kernel(cramgpu_reads R, const uin
             if (m_nc > 0) m_ce0 = R.cigar[m_coff];
         }
         int32_t nf_mine = 0;
-        const int in_tile = min(64, R.n_reads - r0);
+        const int in_tile = min(tile_reads, R.n_reads - r0);
         cramgpu_refwin W{0, 0, 0};
         int wcont = -1;
         for (int k = 0; k < in_tile; k++) {
@@ -99,6 +101,8 @@ __global__ __launch_bounds__(256) void extract_kernel(cramgpu_reads R, const uin
                 wcont = cont;
             }
             int64_t nf = 0;
+            uint32_t hcnt = 0;  // substitution counts of this read, pair k in lane k: one atomic per pair per READ
+                                // (per sweep, 6 M atomics on the 50 counters of two long-read containers took 20 ms)
             if (mapped) {
                 const int nc = lane_bcast(m_nc, k);
                 const int64_t o = WRITE ? lane_bcast(m_off, k) : 0;
@@ -166,15 +170,13 @@ __global__ __launch_bounds__(256) void extract_kernel(cramgpu_reads R, const uin
                                         if (bi >= 0) key = acgtn_index(refb) * 5 + bi;
                                     }
                                     if (sub_hist) {
-                                        // one atomic per distinct (ref, base) pair of the wave
+                                        // pair k is tallied in lane k (flushed once per read, below)
                                         unsigned long long todo = __ballot(key >= 0);
                                         while (todo) {
                                             const int leader = __ffsll((long long)todo) - 1;
                                             const int k0 = __shfl(key, leader);
                                             const unsigned long long same = __ballot(key == k0);
-                                            if (lane == leader)
-                                                atomicAdd((unsigned long long*)&sub_hist[(int64_t)cont * 25 + k0],
-                                                          (unsigned long long)__popcll(same));
+                                            if (lane == k0) hcnt += (uint32_t)__popcll(same);  // lane k counts pair k
                                             todo &= ~same;
                                         }
                                     }
@@ -187,6 +189,8 @@ __global__ __launch_bounds__(256) void extract_kernel(cramgpu_reads R, const uin
                     if (consumes_ref(op)) refoff += len;
                 }
             }
+            if (WRITE && sub_hist && hcnt)
+                atomicAdd((unsigned long long*)&sub_hist[(int64_t)cont * 25 + lane], (unsigned long long)hcnt);
             if (lane == k) nf_mine = (int32_t)nf;
         }
         if (!WRITE && valid) counts[rm] = nf_mine;
@@ -1185,11 +1189,12 @@ hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, c
         }
         return hipGetLastError();
     }
-    const int grid = grid_for_waves(((int64_t)r.n_reads + 63) / 64, 4);  // a wave per tile of 64 reads
+    const int tile_reads = r.max_read_len > kLaneReadMax ? 1 : 64;  // long reads: a wave each
+    const int grid = grid_for_waves(((int64_t)r.n_reads + tile_reads - 1) / tile_reads, 4);
     if (write_pass)
-        hipLaunchKernelGGL(extract_kernel<true>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts);
+        hipLaunchKernelGGL(extract_kernel<true>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts, tile_reads);
     else
-        hipLaunchKernelGGL(extract_kernel<false>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts);
+        hipLaunchKernelGGL(extract_kernel<false>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts, tile_reads);
     return hipGetLastError();
 }
 
