@@ -27,6 +27,35 @@ def main():
         ev[2].record()
         torch.cuda.synchronize()
         print("K3 %.3f ms  matrices+codes %.3f ms  features %d" % (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), n), flush=True)
+    import time
+    big = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    for mode in ("K3 then K1", "K1 alone", "K3, sync + 20 ms sleep, K1", "K3, 1 GB memset, K1", "memset then K1", "memset, gather, K1", "memset, read d_in (sum), K1", "memset, read d_pack, K1"):
+        ms = []
+        for rep in range(3):
+            if "K3" in mode:
+                st.hist.zero_()
+                n = _lib.check(L.cramgpu_extract_features_dev(eng.handle, C.byref(rs_), w["ref"].data_ptr(), C.byref(fs_), st.hist.data_ptr(), s))
+                st.fac.matrices_and_codes(w["reads"], st.feats, st.hist, st.mats)
+            if "matrices" in mode:
+                st.fac.matrices_and_codes(w["reads"], st.feats, st.hist, st.mats)
+            if "sleep" in mode:
+                torch.cuda.synchronize()
+                time.sleep(0.02)
+            if "memset" in mode:
+                big.zero_()
+            if "gather" in mode:
+                eng.gather_dev(st.d_out, st.d_pos, st.d_len, w["n_blocks"], w["max_cap"], st.d_pack, st.d_pack_off)
+            if "read d_in" in mode:
+                junk = w["d_in"][:1 << 28].sum()
+            if "read d_pack" in mode:
+                junk = st.d_pack[:220 << 20].sum()
+            ev[0].record()
+            eng.encode_dev(w["d_in"], st.d_out, w["blocks"], w["n_blocks"], st.d_len, st.d_pos)
+            ev[1].record()
+            eng.gather_dev(st.d_out, st.d_pos, st.d_len, w["n_blocks"], w["max_cap"], st.d_pack, st.d_pack_off)
+            torch.cuda.synchronize()
+            ms.append(ev[0].elapsed_time(ev[1]))
+        print("%-28s K1 ms %s" % (mode, ["%.2f" % m for m in ms]), flush=True)
     st.run(False)
     dec = bench.DecodeStep(dev, eng, w, st)
     dec.prepare()
