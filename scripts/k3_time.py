@@ -29,7 +29,7 @@ def main():
         print("K3 %.3f ms  matrices+codes %.3f ms  features %d" % (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), n), flush=True)
     import time
     big = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-    for mode in ("K3 then K1", "K1 alone", "K3, sync + 20 ms sleep, K1", "K3, 1 GB memset, K1", "memset then K1", "memset, gather, K1", "memset, read d_in (sum), K1", "memset, read d_pack, K1"):
+    for mode in ("K1 alone", "memset then K1", "K3 then K1", "memset, page-touch both, K1"):
         ms = []
         for rep in range(3):
             if "K3" in mode:
@@ -43,6 +43,12 @@ def main():
                 time.sleep(0.02)
             if "memset" in mode:
                 big.zero_()
+            if "page-touch d_out" in mode or "page-touch both" in mode:
+                junk = st.d_out[::4096].sum()
+            if "page-touch d_in" in mode or "page-touch both" in mode:
+                junk2 = w["d_in"][::4096].sum()
+            if "2M-touch" in mode:
+                junk = st.d_out[::1 << 21].sum() + w["d_in"][::1 << 21].sum()
             if "gather" in mode:
                 eng.gather_dev(st.d_out, st.d_pos, st.d_len, w["n_blocks"], w["max_cap"], st.d_pack, st.d_pack_off)
             if "read d_in" in mode:
