@@ -82,6 +82,11 @@ SYMBOLS = {
     "cramgpu_gather_dev": (I32, [P, P, P, P, I32, I32, I32, P, I64, P, P]),
     "cramgpu_rans_encode_batch": (I32, [P, P, I64, P, I64, P, I32, P]),
     "cramgpu_rans_decode_batch": (I32, [P, P, I64, P, I64, P, I32, P]),
+    "cramgpu_host_alloc": (P, [I64]),
+    "cramgpu_host_free": (None, [P]),
+    "cramgpu_rans_submit": (P, [P, I32, P, I64, P, I64, P, I32, P]),
+    "cramgpu_job_poll": (I32, [P]),
+    "cramgpu_job_wait": (I32, [P]),
     "cramgpu_extract_features_dev": (I64, [P, P, P, P, P, P]),
     "cramgpu_substitution_matrix": (None, [P, P]),
     "cramgpu_assign_codes_dev": (I32, [P, I32, P, I32, P, P, P]),

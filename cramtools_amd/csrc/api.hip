@@ -80,7 +80,23 @@ struct PinBuf {
 
 }  // namespace
 
+struct cramgpu_job {
+    cramgpu_ctx* ctx = nullptr;
+    bool busy = false, decode = false, fetched = false;
+    int32_t n = 0;
+    uint8_t* out_arena = nullptr;
+    int32_t* out_len = nullptr;
+    std::vector<cramgpu_block> blocks;
+    DevBuf<uint8_t> d_in, d_out;
+    DevBuf<int32_t> d_len;
+    DevBuf<int64_t> d_pos;
+    PinBuf<int32_t> h_len;
+    PinBuf<int64_t> h_pos;
+    hipEvent_t coded = nullptr, done = nullptr;  // lengths on the host / streams in the caller's arena
+};
+
 struct cramgpu_ctx {
+    cramgpu_job jobs[CRAMGPU_MAX_JOBS];
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
@@ -287,6 +303,11 @@ void cramgpu_close(cramgpu_ctx* c) {
     c->d_in.release(); c->d_out.release(); c->d_pack.release(); c->d_len.release(); c->d_pos.release();
     c->d_off.release(); c->d_err.release(); c->h_stage.release(); c->h_len.release(); c->h_off.release();
     c->d_counts.release(); c->d_list.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_small.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
+    for (auto& j : c->jobs) {
+        j.d_in.release(); j.d_out.release(); j.d_len.release(); j.d_pos.release(); j.h_len.release(); j.h_pos.release();
+        if (j.coded) (void)hipEventDestroy(j.coded);
+        if (j.done) (void)hipEventDestroy(j.done);
+    }
     if (c->staged) (void)hipEventDestroy(c->staged);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -400,6 +421,109 @@ int32_t cramgpu_rans_encode_batch(cramgpu_ctx* c, const uint8_t* in_arena, int64
 int32_t cramgpu_rans_decode_batch(cramgpu_ctx* c, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
                                   int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len) {
     return host_batch(c, false, in_arena, in_bytes, out_arena, out_bytes, blocks, n, out_len);
+}
+
+// ---- asynchronous level 1 ----
+void* cramgpu_host_alloc(int64_t bytes) {
+    void* p = nullptr;
+    if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void cramgpu_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+cramgpu_job* cramgpu_rans_submit(cramgpu_ctx* c, int32_t decode, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                                 int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len) {
+    if (!c || n <= 0 || in_bytes < 0 || out_bytes < 0 || !in_arena || !out_arena || !blocks || !out_len) {
+        fail(CRAMGPU_E_ARG, "submit: bad argument");
+        return nullptr;
+    }
+    for (int32_t i = 0; i < n; i++)
+        if (blocks[i].in_off + blocks[i].in_len > in_bytes || blocks[i].out_off + blocks[i].out_cap > out_bytes) {
+            fail(CRAMGPU_E_ARG, "submit: block outside its arena");
+            return nullptr;
+        }
+    std::lock_guard<std::mutex> lk(c->mu);
+    cramgpu_job* j = nullptr;
+    for (auto& cand : c->jobs)
+        if (!cand.busy) {
+            j = &cand;
+            break;
+        }
+    if (!j) {
+        fail(CRAMGPU_E_ARG, "submit: CRAMGPU_MAX_JOBS jobs outstanding, wait for one first");
+        return nullptr;
+    }
+    auto ok = [&](hipError_t e) { return e == hipSuccess || (fail(CRAMGPU_E_HIP, hipGetErrorString(e)), false); };
+    if (!ok(hipSetDevice(c->device))) return nullptr;
+    hipStream_t s = c->stream;
+    if (!j->coded && !(ok(hipEventCreateWithFlags(&j->coded, hipEventDisableTiming)) &&
+                       ok(hipEventCreateWithFlags(&j->done, hipEventDisableTiming))))
+        return nullptr;
+    if (!(ok(j->d_in.reserve((size_t)align_up(in_bytes, 16) + 16)) && ok(j->d_out.reserve((size_t)align_up(out_bytes, 16) + 16)) &&
+          ok(j->d_len.reserve(n)) && ok(j->d_pos.reserve(n)) && ok(j->h_len.reserve(n)) && ok(j->h_pos.reserve(n))))
+        return nullptr;
+    j->ctx = c;
+    j->decode = decode != 0;
+    j->fetched = false;
+    j->n = n;
+    j->out_arena = out_arena;
+    j->out_len = out_len;
+    j->blocks.assign(blocks, blocks + n);
+    if (!ok(hipMemcpyAsync(j->d_in.p, in_arena, (size_t)in_bytes, hipMemcpyHostToDevice, s))) return nullptr;
+    if (rans_run(c, !j->decode, j->d_in.p, j->d_out.p, blocks, n, j->d_len.p, j->decode ? nullptr : j->d_pos.p, s)) return nullptr;
+    if (!ok(hipMemcpyAsync(j->h_len.p, j->d_len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s))) return nullptr;
+    if (!j->decode && !ok(hipMemcpyAsync(j->h_pos.p, j->d_pos.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, s)))
+        return nullptr;
+    if (!ok(hipEventRecord(j->coded, s))) return nullptr;
+    j->busy = true;
+    return j;
+}
+
+// second half of a job: once the lengths are on the host, one copy per block into the caller's arena
+static int job_fetch(cramgpu_job* j) {
+    if (j->fetched) return 0;
+    cramgpu_ctx* c = j->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(j->coded));
+    for (int32_t i = 0; i < j->n; i++) {
+        const int32_t len = j->h_len.p[i];
+        j->out_len[i] = len;
+        if (len <= 0) continue;
+        const uint8_t* src = j->d_out.p + (j->decode ? j->blocks[i].out_off : j->h_pos.p[i]);
+        HIPCHK(hipMemcpyAsync(j->out_arena + j->blocks[i].out_off, src, (size_t)len, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipEventRecord(j->done, c->stream));
+    j->fetched = true;
+    return 0;
+}
+
+int32_t cramgpu_job_poll(cramgpu_job* j) {
+    if (!j || !j->busy) return fail(CRAMGPU_E_ARG, "poll: no such job");
+    std::lock_guard<std::mutex> lk(j->ctx->mu);
+    if (!j->fetched) {
+        const hipError_t q = hipEventQuery(j->coded);
+        if (q == hipErrorNotReady) return 0;
+        if (q != hipSuccess) return fail(CRAMGPU_E_HIP, hipGetErrorString(q));
+        int rc = job_fetch(j);
+        if (rc) return rc;
+    }
+    const hipError_t q = hipEventQuery(j->done);
+    if (q == hipErrorNotReady) return 0;
+    return q == hipSuccess ? 1 : fail(CRAMGPU_E_HIP, hipGetErrorString(q));
+}
+
+int32_t cramgpu_job_wait(cramgpu_job* j) {
+    if (!j || !j->busy) return fail(CRAMGPU_E_ARG, "wait: no such job");
+    std::lock_guard<std::mutex> lk(j->ctx->mu);
+    int rc = job_fetch(j);
+    if (!rc) {
+        const hipError_t e = hipEventSynchronize(j->done);
+        if (e != hipSuccess) rc = fail(CRAMGPU_E_HIP, hipGetErrorString(e));
+    }
+    j->busy = false;  // the slot (and its device buffers) can take the next submission
+    return rc;
 }
 
 // ---- level 0 ----

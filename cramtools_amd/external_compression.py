@@ -165,6 +165,16 @@ class Engine:
             res.append(out[blocks[i].out_off:blocks[i].out_off + lens[i]].tobytes())
         return res
 
+    # ---- asynchronous host-arena batches (cramgpu_rans_submit / cramgpu_job_wait) ----
+    def submit_compress(self, datas, orders):
+        """Queues one batch (e.g. the external blocks of one container) and returns a job; `job.wait()` -> [bytes].
+        The arenas are pinned memory of the library (cramgpu_host_alloc), what the JNI layer hands to Java as direct
+        ByteBuffers."""
+        return _Job(self, datas, orders, decode=False)
+
+    def submit_uncompress(self, streams):
+        return _Job(self, streams, None, decode=True)
+
     def uncompress_many(self, streams):
         n = len(streams)
         if n == 0:
@@ -187,3 +197,59 @@ class Engine:
                 raise CramGpuError(int(lens[i]), "block %d" % i)
             res.append(out[blocks[i].out_off:blocks[i].out_off + lens[i]].tobytes())
         return res
+
+
+class _Job:
+    """One outstanding cramgpu_rans_submit: owns its pinned arenas until wait()."""
+
+    def __init__(self, eng, items, orders, decode):
+        L = _lib.lib()
+        n = len(items)
+        if decode:
+            raws = []
+            for s in items:
+                b = np.frombuffer(bytes(s), np.uint8)
+                raws.append(0 if b.size == 0 else _lib.check(L.cramgpu_rans_raw_size(b.ctypes.data, b.size)))
+            self.blocks, self.in_bytes, self.out_bytes = Engine.plan_decode([len(s) for s in items], raws)
+        else:
+            self.blocks, self.in_bytes, self.out_bytes = Engine.plan_encode([len(d) for d in items], orders)
+        self.n, self.eng = n, eng
+        self.h_in = L.cramgpu_host_alloc(self.in_bytes)
+        self.h_out = L.cramgpu_host_alloc(self.out_bytes)
+        self.h_len = L.cramgpu_host_alloc(4 * max(n, 1))
+        if not (self.h_in and self.h_out and self.h_len):
+            raise CramGpuError(_lib.E_HIP, "cramgpu_host_alloc failed")
+        arena = np.ctypeslib.as_array(C.cast(self.h_in, C.POINTER(C.c_uint8)), shape=(self.in_bytes,))
+        arena[:] = 0
+        for i, d in enumerate(items):
+            arena[self.blocks[i].in_off:self.blocks[i].in_off + len(d)] = np.frombuffer(bytes(d), np.uint8)
+        self.job = L.cramgpu_rans_submit(eng.handle, 1 if decode else 0, self.h_in, self.in_bytes, self.h_out, self.out_bytes,
+                                         C.addressof(self.blocks), n, self.h_len)
+        if not self.job:
+            self._free()
+            raise CramGpuError(_lib.E_ARG, _lib.last_error())
+
+    def _free(self):
+        L = _lib.lib()
+        for name in ("h_in", "h_out", "h_len"):
+            p = getattr(self, name, None)
+            if p:
+                L.cramgpu_host_free(p)
+                setattr(self, name, None)
+
+    def done(self):
+        return _lib.check(_lib.lib().cramgpu_job_poll(self.job)) == 1
+
+    def wait(self):
+        try:
+            _lib.check(_lib.lib().cramgpu_job_wait(self.job))
+            out = np.ctypeslib.as_array(C.cast(self.h_out, C.POINTER(C.c_uint8)), shape=(self.out_bytes,))
+            lens = np.ctypeslib.as_array(C.cast(self.h_len, C.POINTER(C.c_int32)), shape=(max(self.n, 1),))
+            res = []
+            for i in range(self.n):
+                if lens[i] < 0:
+                    raise CramGpuError(int(lens[i]), "block %d" % i)
+                res.append(out[self.blocks[i].out_off:self.blocks[i].out_off + lens[i]].tobytes())
+            return res
+        finally:
+            self._free()

@@ -174,7 +174,7 @@ using std::min;
 
 // ---- runtime API ----
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
@@ -197,5 +197,6 @@ inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline long long clock64() { return 0; }

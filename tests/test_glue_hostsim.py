@@ -42,6 +42,7 @@ def test_rans_gpu_test_bodies(hostsim, kat1, orc):
         t.test_empty_short_and_errors(xc, orc)
         t.test_decoder_accepts_oracle_streams(eng, orc)
         t.test_corrupt_streams_do_not_crash(eng, orc)
+        t.test_async_jobs(eng, orc)
         import test_foreign_streams as tf
         tf.check_library_decodes(xc)  # tables summing to 4096, F = 4096 in both spellings
         # device-arena entry points + gather, as bench.py drives them

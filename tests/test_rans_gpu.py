@@ -102,3 +102,28 @@ def test_corrupt_streams_do_not_crash(engine, orc):
             t = t[:1] + (len(t) - 9).to_bytes(4, "little") + t[5:]
             with pytest.raises(RuntimeError):
                 engine.uncompress_many([t])
+
+
+def test_async_jobs(engine, orc):
+    """cramgpu_rans_submit / poll / wait: several containers' worth of blocks queued before the first wait give what
+    the synchronous batch gives; a fifth outstanding job is refused; decode jobs round-trip."""
+    rng = np.random.default_rng(3)
+    batches = []
+    for k in range(4):
+        datas = [rng.integers(0, 5 + 40 * k, n, dtype=np.uint8).tobytes() for n in (30000 + k, 777, 5, 12000)]
+        batches.append((datas, [1, 0, 1, 1]))
+    jobs = [engine.submit_compress(d, o) for d, o in batches]
+    from cramtools_amd._lib import CramGpuError
+    with pytest.raises(CramGpuError):
+        engine.submit_compress(*batches[0])
+    outs = []
+    for (d, o), j in zip(batches, jobs):
+        got = j.wait()
+        assert got == [orc.rans(x, y) for x, y in zip(d, o)]
+        outs.append(got)
+    djobs = [engine.submit_uncompress(o) for o in outs]
+    while not djobs[0].done():
+        pass
+    for (d, _), j in zip(batches, djobs):
+        assert j.wait() == d
+    assert engine.compress_many(*batches[1]) == outs[1]  # the synchronous path still works afterwards
