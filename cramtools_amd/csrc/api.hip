@@ -80,7 +80,30 @@ struct PinBuf {
 
 }  // namespace
 
+// What one rANS launch needs besides the arenas: descriptor / permutation staging, a ticket word, the per-workgroup
+// global scratch.  The context has one set (synchronous calls, stream-ordered); every asynchronous job slot has its
+// own set and its own stream, so that the (small, latency-bound) launches of several jobs overlap on the device.
+struct LaunchRes {
+    hipEvent_t staged = nullptr;  // completion of the last descriptor upload (pinned staging reuse)
+    bool staged_pending = false;
+    PinBuf<cramgpu_block> h_desc;
+    PinBuf<int32_t> h_perm;
+    DevBuf<cramgpu_block> d_desc;
+    DevBuf<int32_t> d_perm;
+    DevBuf<uint32_t> tickets;
+    uint32_t ticket_next = 0;
+    DevBuf<uint8_t> enc_gs, dec_gs;
+    void release() {
+        h_desc.release(); h_perm.release(); d_desc.release(); d_perm.release(); tickets.release();
+        enc_gs.release(); dec_gs.release();
+        if (staged) (void)hipEventDestroy(staged);
+        staged = nullptr;
+    }
+};
+
 struct cramgpu_job {
+    LaunchRes res;
+    hipStream_t stream = nullptr;
     cramgpu_ctx* ctx = nullptr;
     bool busy = false, decode = false, fetched = false;
     int32_t n = 0;
@@ -100,20 +123,13 @@ struct cramgpu_ctx {
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t staged = nullptr;  // completion of the last descriptor upload (pinned staging reuse)
-    bool staged_pending = false;
+    LaunchRes res;
     std::mutex mu;
     // rANS launch geometry
     int tab_bytes = 0, dec_tab_bytes = 0, enc_wpc = 0, dec_wpc = 0, n_waves_enc = 0, n_waves_dec = 0;
     size_t enc_lds = 0, dec_lds = 0;
-    DevBuf<uint8_t> enc_gs, dec_gs;
-    DevBuf<uint32_t> rcp_tab, tickets;
-    uint32_t ticket_next = 0;
+    DevBuf<uint32_t> rcp_tab;
     // descriptor staging
-    PinBuf<cramgpu_block> h_desc;
-    PinBuf<int32_t> h_perm;
-    DevBuf<cramgpu_block> d_desc;
-    DevBuf<int32_t> d_perm;
     // host-batch / level-0 staging
     DevBuf<uint8_t> d_in, d_out, d_pack;
     DevBuf<int32_t> d_len;
@@ -142,45 +158,54 @@ constexpr int kTicketSlots = 256;
 hipStream_t pick(cramgpu_ctx*, void* stream) { return (hipStream_t)stream; }
 
 // uploads descriptors + LPT permutation, returns device pointers valid in stream order
-int stage_blocks(cramgpu_ctx* c, const cramgpu_block* blocks, int32_t n, hipStream_t s, bool encode) {
-    if (c->staged_pending) {
-        HIPCHK(hipEventSynchronize(c->staged));
-        c->staged_pending = false;
+int stage_blocks(LaunchRes& r, const cramgpu_block* blocks, int32_t n, hipStream_t s, bool encode) {
+    if (!r.staged) HIPCHK(hipEventCreateWithFlags(&r.staged, hipEventDisableTiming));
+    if (r.staged_pending) {
+        HIPCHK(hipEventSynchronize(r.staged));
+        r.staged_pending = false;
     }
-    HIPCHK(c->h_desc.reserve(n));
-    HIPCHK(c->h_perm.reserve(n));
-    HIPCHK(c->d_desc.reserve(n));
-    HIPCHK(c->d_perm.reserve(n));
+    HIPCHK(r.h_desc.reserve(n));
+    HIPCHK(r.h_perm.reserve(n));
+    HIPCHK(r.d_desc.reserve(n));
+    HIPCHK(r.d_perm.reserve(n));
     for (int32_t i = 0; i < n; i++) {
         const cramgpu_block& b = blocks[i];
         if (b.in_off < 0 || b.out_off < 0 || (b.in_off % CRAMGPU_ARENA_ALIGN) || (encode && (b.out_off % CRAMGPU_ARENA_ALIGN)))
             return fail(CRAMGPU_E_ARG, "block offsets must be non-negative multiples of CRAMGPU_ARENA_ALIGN");
         if (b.in_len < 0 || b.out_cap < 0) return fail(CRAMGPU_E_ARG, "negative block size");
     }
-    memcpy(c->h_desc.p, blocks, (size_t)n * sizeof(cramgpu_block));
-    std::iota(c->h_perm.p, c->h_perm.p + n, 0);
-    std::stable_sort(c->h_perm.p, c->h_perm.p + n,
+    memcpy(r.h_desc.p, blocks, (size_t)n * sizeof(cramgpu_block));
+    std::iota(r.h_perm.p, r.h_perm.p + n, 0);
+    std::stable_sort(r.h_perm.p, r.h_perm.p + n,
                      [&](int32_t x, int32_t y) { return blocks[x].in_len > blocks[y].in_len; });
-    HIPCHK(hipMemcpyAsync(c->d_desc.p, c->h_desc.p, (size_t)n * sizeof(cramgpu_block), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->d_perm.p, c->h_perm.p, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(hipEventRecord(c->staged, s));
-    c->staged_pending = true;
+    HIPCHK(hipMemcpyAsync(r.d_desc.p, r.h_desc.p, (size_t)n * sizeof(cramgpu_block), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(r.d_perm.p, r.h_perm.p, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(r.staged, s));
+    r.staged_pending = true;
     return 0;
 }
 
-int rans_run(cramgpu_ctx* c, bool encode, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks, int32_t n,
-             int32_t* d_out_len, int64_t* d_out_pos, hipStream_t s) {
+int rans_run(cramgpu_ctx* c, LaunchRes& r, bool encode, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,
+             int32_t n, int32_t* d_out_len, int64_t* d_out_pos, hipStream_t s) {
     if (n == 0) return 0;
     HIPCHK(hipSetDevice(c->device));
-    int rc = stage_blocks(c, blocks, n, s, encode);
+    int rc = stage_blocks(r, blocks, n, s, encode);
     if (rc) return rc;
-    uint32_t* ticket = c->tickets.p + (c->ticket_next++ % kTicketSlots);
+    // resident workgroups of this launch and their global scratch (grown on demand: a job of a few containers needs
+    // a few workgroups' worth, the synchronous calls of a whole read set all of them)
+    const int groups = std::min(n, encode ? c->n_waves_enc : c->n_waves_dec);
+    HIPCHK(r.tickets.reserve(kTicketSlots));
+    if (encode)
+        HIPCHK(r.enc_gs.reserve((size_t)groups * ENC_GSCRATCH_BYTES));
+    else
+        HIPCHK(r.dec_gs.reserve((size_t)groups * DEC_GSCRATCH_BYTES));
+    uint32_t* ticket = r.tickets.p + (r.ticket_next++ % kTicketSlots);
     HIPCHK(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
     RansArgs a{};
     a.in = d_in;
     a.out = d_out;
-    a.desc = c->d_desc.p;
-    a.perm = c->d_perm.p;
+    a.desc = r.d_desc.p;
+    a.perm = r.d_perm.p;
     a.n_blocks = n;
     a.out_len = d_out_len;
     a.out_pos = d_out_pos;
@@ -194,8 +219,8 @@ int rans_run(cramgpu_ctx* c, bool encode, const uint8_t* d_in, uint8_t* d_out, c
         a.prof = c->d_prof.p;
     }
     if (encode) {
-        a.gscratch = c->enc_gs.p;
-        HIPCHK(launch_rans_encode(a, std::min(n, c->n_waves_enc), c->enc_lds, s));
+        a.gscratch = r.enc_gs.p;
+        HIPCHK(launch_rans_encode(a, groups, c->enc_lds, s));
         if (a.prof) {
             std::vector<unsigned long long> h((size_t)n * 8);
             HIPCHK(hipMemcpyAsync(h.data(), a.prof, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -211,8 +236,8 @@ int rans_run(cramgpu_ctx* c, bool encode, const uint8_t* d_in, uint8_t* d_out, c
                     r[4] ? (double)r[5] / (32.0 * r[4]) : 0.0, r[6]);
         }
     } else {
-        a.gscratch = c->dec_gs.p;
-        HIPCHK(launch_rans_decode(a, std::min(n, c->n_waves_dec), c->dec_lds, s));
+        a.gscratch = r.dec_gs.p;
+        HIPCHK(launch_rans_decode(a, groups, c->dec_lds, s));
     }
     return 0;
 }
@@ -279,10 +304,7 @@ cramgpu_ctx* cramgpu_open(int32_t device_index) {
     c->n_waves_enc = c->n_cu * c->enc_wpc;
     c->n_waves_dec = c->n_cu * c->dec_wpc;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&c->staged, hipEventDisableTiming) == hipSuccess &&
-              c->enc_gs.reserve((size_t)c->n_waves_enc * ENC_GSCRATCH_BYTES) == hipSuccess &&
-              c->dec_gs.reserve((size_t)c->n_waves_dec * DEC_GSCRATCH_BYTES) == hipSuccess &&
-              c->rcp_tab.reserve(4096) == hipSuccess && c->tickets.reserve(kTicketSlots) == hipSuccess &&
+              c->rcp_tab.reserve(4096) == hipSuccess &&
               c->d_err.reserve(16) == hipSuccess && c->d_total.reserve(16) == hipSuccess &&
               c->h_total.reserve(16) == hipSuccess && c->d_small.reserve(65536) == hipSuccess;
     if (ok) ok = launch_rcp_init(c->rcp_tab.p, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
@@ -298,17 +320,17 @@ void cramgpu_close(cramgpu_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    c->enc_gs.release(); c->dec_gs.release(); c->rcp_tab.release(); c->tickets.release();
-    c->h_desc.release(); c->h_perm.release(); c->d_desc.release(); c->d_perm.release();
+    c->res.release(); c->rcp_tab.release();
     c->d_in.release(); c->d_out.release(); c->d_pack.release(); c->d_len.release(); c->d_pos.release();
     c->d_off.release(); c->d_err.release(); c->h_stage.release(); c->h_len.release(); c->h_off.release();
     c->d_counts.release(); c->d_list.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_small.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
     for (auto& j : c->jobs) {
         j.d_in.release(); j.d_out.release(); j.d_len.release(); j.d_pos.release(); j.h_len.release(); j.h_pos.release();
+        j.res.release();
+        if (j.stream) (void)hipStreamDestroy(j.stream);
         if (j.coded) (void)hipEventDestroy(j.coded);
         if (j.done) (void)hipEventDestroy(j.done);
     }
-    if (c->staged) (void)hipEventDestroy(c->staged);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -333,7 +355,7 @@ int32_t cramgpu_rans_encode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_
     if (!c || n < 0 || (n > 0 && (!d_in || !d_out || !blocks || !d_out_len || !d_out_pos)))
         return fail(CRAMGPU_E_ARG, "cramgpu_rans_encode_dev: bad argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    return rans_run(c, true, d_in, d_out, blocks, n, d_out_len, d_out_pos, pick(c, stream));
+    return rans_run(c, c->res, true, d_in, d_out, blocks, n, d_out_len, d_out_pos, pick(c, stream));
 }
 
 int32_t cramgpu_rans_decode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,
@@ -341,7 +363,7 @@ int32_t cramgpu_rans_decode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_
     if (!c || n < 0 || (n > 0 && (!d_in || !d_out || !blocks || !d_out_len)))
         return fail(CRAMGPU_E_ARG, "cramgpu_rans_decode_dev: bad argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    return rans_run(c, false, d_in, d_out, blocks, n, d_out_len, nullptr, pick(c, stream));
+    return rans_run(c, c->res, false, d_in, d_out, blocks, n, d_out_len, nullptr, pick(c, stream));
 }
 
 int32_t cramgpu_gather_dev(cramgpu_ctx* c, const uint8_t* d_src, const int64_t* d_pos, const int32_t* d_len, int32_t n,
@@ -377,7 +399,7 @@ static int32_t host_batch(cramgpu_ctx* c, bool encode, const uint8_t* in_arena, 
     HIPCHK(c->h_len.reserve(n));
     HIPCHK(hipMemcpyAsync(c->d_in.p, in_arena, (size_t)in_bytes, hipMemcpyHostToDevice, s));
     if (!encode) {
-        int rc = rans_run(c, false, c->d_in.p, c->d_out.p, blocks, n, c->d_len.p, nullptr, s);
+        int rc = rans_run(c, c->res, false, c->d_in.p, c->d_out.p, blocks, n, c->d_len.p, nullptr, s);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(c->h_len.p, c->d_len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -394,7 +416,7 @@ static int32_t host_batch(cramgpu_ctx* c, bool encode, const uint8_t* in_arena, 
     HIPCHK(c->d_pos.reserve(n));
     HIPCHK(c->d_off.reserve((size_t)n + 1));
     HIPCHK(c->h_off.reserve((size_t)n + 1));
-    int rc = rans_run(c, true, c->d_in.p, c->d_out.p, blocks, n, c->d_len.p, c->d_pos.p, s);
+    int rc = rans_run(c, c->res, true, c->d_in.p, c->d_out.p, blocks, n, c->d_len.p, c->d_pos.p, s);
     if (rc) return rc;
     // pack on the device so that only compressed bytes cross PCIe
     HIPCHK(c->d_pack.reserve((size_t)align_up(out_bytes, 16) + (size_t)n * 16 + 16));
@@ -457,10 +479,11 @@ cramgpu_job* cramgpu_rans_submit(cramgpu_ctx* c, int32_t decode, const uint8_t* 
     }
     auto ok = [&](hipError_t e) { return e == hipSuccess || (fail(CRAMGPU_E_HIP, hipGetErrorString(e)), false); };
     if (!ok(hipSetDevice(c->device))) return nullptr;
-    hipStream_t s = c->stream;
     if (!j->coded && !(ok(hipEventCreateWithFlags(&j->coded, hipEventDisableTiming)) &&
-                       ok(hipEventCreateWithFlags(&j->done, hipEventDisableTiming))))
+                       ok(hipEventCreateWithFlags(&j->done, hipEventDisableTiming)) &&
+                       ok(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking))))
         return nullptr;
+    hipStream_t s = j->stream;  // every job slot has its own stream: the launches of outstanding jobs overlap
     if (!(ok(j->d_in.reserve((size_t)align_up(in_bytes, 16) + 16)) && ok(j->d_out.reserve((size_t)align_up(out_bytes, 16) + 16)) &&
           ok(j->d_len.reserve(n)) && ok(j->d_pos.reserve(n)) && ok(j->h_len.reserve(n)) && ok(j->h_pos.reserve(n))))
         return nullptr;
@@ -472,7 +495,8 @@ cramgpu_job* cramgpu_rans_submit(cramgpu_ctx* c, int32_t decode, const uint8_t* 
     j->out_len = out_len;
     j->blocks.assign(blocks, blocks + n);
     if (!ok(hipMemcpyAsync(j->d_in.p, in_arena, (size_t)in_bytes, hipMemcpyHostToDevice, s))) return nullptr;
-    if (rans_run(c, !j->decode, j->d_in.p, j->d_out.p, blocks, n, j->d_len.p, j->decode ? nullptr : j->d_pos.p, s)) return nullptr;
+    if (rans_run(c, j->res, !j->decode, j->d_in.p, j->d_out.p, blocks, n, j->d_len.p, j->decode ? nullptr : j->d_pos.p, s))
+        return nullptr;
     if (!ok(hipMemcpyAsync(j->h_len.p, j->d_len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s))) return nullptr;
     if (!j->decode && !ok(hipMemcpyAsync(j->h_pos.p, j->d_pos.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, s)))
         return nullptr;
@@ -492,9 +516,9 @@ static int job_fetch(cramgpu_job* j) {
         j->out_len[i] = len;
         if (len <= 0) continue;
         const uint8_t* src = j->d_out.p + (j->decode ? j->blocks[i].out_off : j->h_pos.p[i]);
-        HIPCHK(hipMemcpyAsync(j->out_arena + j->blocks[i].out_off, src, (size_t)len, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(j->out_arena + j->blocks[i].out_off, src, (size_t)len, hipMemcpyDeviceToHost, j->stream));
     }
-    HIPCHK(hipEventRecord(j->done, c->stream));
+    HIPCHK(hipEventRecord(j->done, j->stream));
     j->fetched = true;
     return 0;
 }

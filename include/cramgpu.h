@@ -123,13 +123,13 @@ int32_t cramgpu_rans_decode_batch(cramgpu_ctx* ctx, const uint8_t* in_arena, int
 /* Asynchronous form of the host-buffer batch: what TransformerJob threads (paralell/TransformerJob.java:16-41) and
  * CRAMContainerAsynchWriter.Batch.run (CRAMContainerAsynchWriter.java:139-149) do with a thread per container, the
  * library does with a queue per context: cramgpu_rans_submit copies the input arena to the GPU, codes the blocks and
- * fetches lengths with hipMemcpyAsync on the context's own stream and returns at once; the Java thread marshals the
+ * fetches lengths with hipMemcpyAsync on the job slot's own stream and returns at once; the Java thread marshals the
  * next container meanwhile.  cramgpu_job_wait brings the streams into out_arena (as cramgpu_rans_*_batch leaves
  * them) and out_len, and releases the job; cramgpu_job_poll says whether wait would block (1 = finished).
  * Arenas and out_len must stay valid and untouched from submit to wait; for copies that overlap host work they
- * should come from cramgpu_host_alloc (pinned memory, exposed to Java as direct ByteBuffers).  Jobs of one context
- * run in submission order; at most CRAMGPU_MAX_JOBS may be outstanding (submit fails with CRAMGPU_E_ARG beyond).
- * Use one context per GPU, or two to overlap one job's copies with another's kernels. */
+ * should come from cramgpu_host_alloc (pinned memory, exposed to Java as direct ByteBuffers).  At most
+ * CRAMGPU_MAX_JOBS may be outstanding per context (submit fails with CRAMGPU_E_ARG beyond); every slot has its own
+ * stream and launch resources, so the copies and kernels of outstanding jobs overlap.  One context per GPU. */
 #define CRAMGPU_MAX_JOBS 4
 typedef struct cramgpu_job cramgpu_job;
 void* cramgpu_host_alloc(int64_t bytes);
