@@ -206,7 +206,8 @@ class DecodeStep:
         _lib.check(L.cramgpu_restore_bases_dev(
             self.eng.handle, reads.n, reads.read_len.data_ptr(), reads.aln_start.data_ptr(), self.rflags.data_ptr(),
             reads.read_cont.data_ptr(), reads.n_cont, reads.win.data_ptr(), C.byref(fs), reads.bases.data_ptr(),
-            reads.base_off.data_ptr(), w["ref"].data_ptr(), self.mats_h.ctypes.data, self.bases.data_ptr(),
+            reads.base_off.data_ptr(), int(reads.bases.numel()), w["ref"].data_ptr(), self.mats_h.ctypes.data,
+            self.bases.data_ptr(),
             reads.base_off.data_ptr(), self.st_b.data_ptr(), s))
         # the qualities of a read sit in the decoded arena inside its container's QS block (q_off), restored in place
         _lib.check(L.cramgpu_restore_quals_dev(self.eng.handle, reads.n, reads.read_len.data_ptr(), self.rflags.data_ptr(),

@@ -13,28 +13,34 @@ LIB_PATH = os.path.join(_HERE, "libcramgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 E_INPUT_LENGTH, E_OUT_TOO_SMALL, E_INSUFFICIENT, E_ORDER, E_CORRUPT = -1, -2, -3, -4, -5
-E_ARG, E_HIP, E_NO_DEVICE, E_JAVA_THROWS = -6, -7, -8, -9
+E_ARG, E_HIP, E_NO_DEVICE, E_JAVA_THROWS, E_UNSUPPORTED = -6, -7, -8, -9, -10
 ARENA_ALIGN = 16
 RF_UNMAPPED, RF_NULL_QUALS, RF_NO_BASES, RF_UNKNOWN_BASES, RF_FORCE_QS, RF_SKIP = 1, 2, 4, 8, 16, 32
 
-# the reference's exception messages
+# the reference's exception messages; %-forms are filled by the caller that holds N / X
 MESSAGES = {
     E_INPUT_LENGTH: "Incorrect input length.",
-    E_OUT_TOO_SMALL: "Output buffer too small to fit the raw bytes.",
+    E_OUT_TOO_SMALL: "Output buffer too small to fit %d bytes.",
     E_INSUFFICIENT: "Insufficient buffer size.",
-    E_ORDER: "Unknown rANS order",
+    E_ORDER: "Unknown rANS order: %s",
     E_CORRUPT: "Malformed rANS stream",
     E_ARG: "Bad argument",
     E_HIP: "HIP runtime error",
     E_NO_DEVICE: "No MI355X device visible (libcramgpu has no CPU path)",
     E_JAVA_THROWS: "The reference would throw on this record",
+    E_UNSUPPORTED: "Lossy-model term needs the coverage / mismatch tracks, which libcramgpu does not build",
 }
 
 
 class CramGpuError(RuntimeError):
-    def __init__(self, code, detail=""):
+    """`arg` fills the N / X of the reference's message (RANS#uncompress "…to fit N bytes.", RANS.ORDER.fromInt
+    "Unknown rANS order: X"); without it the placeholder stays generic."""
+
+    def __init__(self, code, detail="", arg=None):
         self.code = code
         msg = MESSAGES.get(code, "error %d" % code)
+        if "%" in msg:
+            msg = msg % (arg,) if arg is not None else msg.replace(" %d bytes", " the raw bytes").replace(": %s", "")
         super().__init__(msg + (": " + detail if detail else ""))
 
 
@@ -91,11 +97,11 @@ SYMBOLS = {
     "cramgpu_substitution_matrix": (None, [P, P]),
     "cramgpu_assign_codes_dev": (I32, [P, I32, P, I32, P, P, P]),
     "cramgpu_matrices_assign_codes_dev": (I32, [P, I32, P, I32, P, P, P, P]),
-    "cramgpu_restore_bases_dev": (I32, [P, I32, P, P, P, P, I32, P, P, P, P, P, P, P, P, P, P]),
+    "cramgpu_restore_bases_dev": (I32, [P, I32, P, P, P, P, I32, P, P, P, P, I64, P, P, P, P, P, P]),
     "cramgpu_restore_quals_dev": (I32, [P, I32, P, P, P, U8, P, P, P, P]),
     "cramgpu_parse_policies": (I32, [C.c_char_p, P, I32]),
     "cramgpu_lossy_quals_dev": (I32, [P, P, P, P, I32, P, I32, P, P, P, P]),
-    "cramgpu_tracks_windows": (I32, [I32, P, P, P, P, P, I32, I64, I32, P]),
+    "cramgpu_tracks_windows": (I32, [I32, P, P, P, P, P, I32, I64, I32, P, P]),
     "cramgpu_merge_quality_features_dev": (I64, [P, I32, P, P, P, P, P, P, P, P]),
 }
 

@@ -118,8 +118,27 @@ struct cramgpu_job {
     hipEvent_t coded = nullptr, done = nullptr;  // lengths on the host / streams in the caller's arena
 };
 
+// Small host tables (code tables, policies) on their way to the device: a ring of pinned slots, each with its own
+// device copy and an event that says when the kernels reading that copy have been queued behind it.  A *_dev call
+// therefore never waits for the device; only a ring that wraps onto a slot whose upload has not run yet waits.
+constexpr int kSmallSlots = 8;
+struct SmallSlot {
+    PinBuf<uint8_t> h;
+    DevBuf<uint8_t> d;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+};
+
 struct cramgpu_ctx {
     cramgpu_job jobs[CRAMGPU_MAX_JOBS];
+    SmallSlot small[kSmallSlots];
+    int small_next = 0;
+    // Calls on one context share scratch (descriptor staging, LPT permutation, per-workgroup tables, counters).  The
+    // mutex orders them on the host; this event orders them on the DEVICE when consecutive calls use different
+    // streams: every call records it behind its last launch, the next call's stream waits for it first.
+    hipEvent_t last_use = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool last_valid = false;
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
@@ -143,7 +162,6 @@ struct cramgpu_ctx {
     DevBuf<int32_t> d_list;
     DevBuf<int64_t> d_total, d_scan_ws;
     PinBuf<int64_t> h_total;
-    DevBuf<uint8_t> d_small;   // matrix tables, policies
     DevBuf<uint8_t> d_maskws, d_codes25;
     DevBuf<unsigned long long> d_prof;  // CRAMGPU_PROF=1
     bool prof_on = false;
@@ -156,6 +174,50 @@ constexpr int kTicketSlots = 256;
 // NULL is HIP's own null stream (what torch calls the default stream), NOT the context's private stream: work the
 // caller queued on the null stream before the call is ordered before ours.
 hipStream_t pick(cramgpu_ctx*, void* stream) { return (hipStream_t)stream; }
+
+// Device-side ordering of consecutive calls on one context (see cramgpu_ctx::last_use).  enter() before the first
+// touch of shared scratch, leave() behind the last launch of the call; both under the context mutex.
+int enter(cramgpu_ctx* c, hipStream_t s) {
+    HIPCHK(hipSetDevice(c->device));
+    if (c->last_valid && c->last_stream != s) HIPCHK(hipStreamWaitEvent(s, c->last_use, 0));
+    return 0;
+}
+int leave(cramgpu_ctx* c, hipStream_t s) {
+    if (!c->last_use) HIPCHK(hipEventCreateWithFlags(&c->last_use, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->last_use, s));
+    c->last_stream = s;
+    c->last_valid = true;
+    return 0;
+}
+struct CallScope {  // leave() on every exit path of an entry point
+    cramgpu_ctx* c;
+    hipStream_t s;
+    ~CallScope() { (void)leave(c, s); }
+};
+
+// Copies a small host table into the next ring slot and queues its upload on s; *dptr is valid in stream order.
+// Call release_small() after the kernels that read it have been launched.
+int stage_small(cramgpu_ctx* c, const void* src, size_t bytes, hipStream_t s, uint8_t** dptr, SmallSlot** slot) {
+    SmallSlot& sl = c->small[c->small_next];
+    c->small_next = (c->small_next + 1) % kSmallSlots;
+    if (!sl.ev) HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (sl.pending) {
+        HIPCHK(hipEventSynchronize(sl.ev));
+        sl.pending = false;
+    }
+    HIPCHK(sl.h.reserve(bytes));
+    HIPCHK(sl.d.reserve(bytes));
+    memcpy(sl.h.p, src, bytes);
+    HIPCHK(hipMemcpyAsync(sl.d.p, sl.h.p, bytes, hipMemcpyHostToDevice, s));
+    *dptr = sl.d.p;
+    *slot = &sl;
+    return 0;
+}
+int release_small(SmallSlot* sl, hipStream_t s) {
+    HIPCHK(hipEventRecord(sl->ev, s));
+    sl->pending = true;
+    return 0;
+}
 
 // uploads descriptors + LPT permutation, returns device pointers valid in stream order
 int stage_blocks(LaunchRes& r, const cramgpu_block* blocks, int32_t n, hipStream_t s, bool encode) {
@@ -283,6 +345,7 @@ cramgpu_ctx* cramgpu_open(int32_t device_index) {
     cramgpu_ctx* c = new cramgpu_ctx();
     c->device = device_index;
     c->n_cu = prop.multiProcessorCount;
+    records_set_cu_count(c->n_cu);
     const int lds_per_cu = 160 * 1024;
     // LDS table region of a resident rANS workgroup: 4 encoder groups (2 waves each) per CU fill the 160 KiB
     c->tab_bytes = env_int("CRAMGPU_TAB_BYTES", 35 * 1024) & ~15;
@@ -306,7 +369,7 @@ cramgpu_ctx* cramgpu_open(int32_t device_index) {
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               c->rcp_tab.reserve(4096) == hipSuccess &&
               c->d_err.reserve(16) == hipSuccess && c->d_total.reserve(16) == hipSuccess &&
-              c->h_total.reserve(16) == hipSuccess && c->d_small.reserve(65536) == hipSuccess;
+              c->h_total.reserve(16) == hipSuccess;
     if (ok) ok = launch_rcp_init(c->rcp_tab.p, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
     if (!ok) {
         fail(CRAMGPU_E_HIP, "cramgpu_open: allocation or init kernel failed", hipGetLastError());
@@ -323,7 +386,13 @@ void cramgpu_close(cramgpu_ctx* c) {
     c->res.release(); c->rcp_tab.release();
     c->d_in.release(); c->d_out.release(); c->d_pack.release(); c->d_len.release(); c->d_pos.release();
     c->d_off.release(); c->d_err.release(); c->h_stage.release(); c->h_len.release(); c->h_off.release();
-    c->d_counts.release(); c->d_list.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_small.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
+    c->d_counts.release(); c->d_list.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
+    for (auto& sl : c->small) {
+        sl.h.release();
+        sl.d.release();
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+    }
+    if (c->last_use) (void)hipEventDestroy(c->last_use);
     for (auto& j : c->jobs) {
         j.d_in.release(); j.d_out.release(); j.d_len.release(); j.d_pos.release(); j.h_len.release(); j.h_pos.release();
         j.res.release();
@@ -355,7 +424,10 @@ int32_t cramgpu_rans_encode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_
     if (!c || n < 0 || (n > 0 && (!d_in || !d_out || !blocks || !d_out_len || !d_out_pos)))
         return fail(CRAMGPU_E_ARG, "cramgpu_rans_encode_dev: bad argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    return rans_run(c, c->res, true, d_in, d_out, blocks, n, d_out_len, d_out_pos, pick(c, stream));
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    return rans_run(c, c->res, true, d_in, d_out, blocks, n, d_out_len, d_out_pos, s);
 }
 
 int32_t cramgpu_rans_decode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,
@@ -363,7 +435,10 @@ int32_t cramgpu_rans_decode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_
     if (!c || n < 0 || (n > 0 && (!d_in || !d_out || !blocks || !d_out_len)))
         return fail(CRAMGPU_E_ARG, "cramgpu_rans_decode_dev: bad argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    return rans_run(c, c->res, false, d_in, d_out, blocks, n, d_out_len, nullptr, pick(c, stream));
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    return rans_run(c, c->res, false, d_in, d_out, blocks, n, d_out_len, nullptr, s);
 }
 
 int32_t cramgpu_gather_dev(cramgpu_ctx* c, const uint8_t* d_src, const int64_t* d_pos, const int32_t* d_len, int32_t n,
@@ -373,8 +448,10 @@ int32_t cramgpu_gather_dev(cramgpu_ctx* c, const uint8_t* d_src, const int64_t* 
         return fail(CRAMGPU_E_ARG, "cramgpu_gather_dev: bad argument");
     if (n == 0) return 0;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(launch_gather(d_src, d_pos, d_len, n, align, d_dst, dst_cap, d_dst_off, c->d_err.p, max_len, pick(c, stream)));
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(launch_gather(d_src, d_pos, d_len, n, align, d_dst, dst_cap, d_dst_off, c->d_err.p, max_len, s));
     return 0;
 }
 
@@ -391,8 +468,9 @@ static int32_t host_batch(cramgpu_ctx* c, bool encode, const uint8_t* in_arena, 
         max_cap = std::max<int64_t>(max_cap, blocks[i].out_cap);
     }
     std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
     HIPCHK(c->d_in.reserve((size_t)align_up(in_bytes, 16) + 16));
     HIPCHK(c->d_out.reserve((size_t)align_up(out_bytes, 16) + 16));
     HIPCHK(c->d_len.reserve(n));
@@ -426,6 +504,9 @@ static int32_t host_batch(cramgpu_ctx* c, bool encode, const uint8_t* in_arena, 
     HIPCHK(hipMemcpyAsync(c->h_off.p, c->d_off.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const int64_t packed = c->h_off.p[n];
+    // gather_scan_kernel skips every copy when the packed size exceeds the destination (overlapping slots can make
+    // it larger than out_bytes + 16 n): the bytes of d_pack would be stale
+    if (packed > (int64_t)c->d_pack.cap) return fail(CRAMGPU_E_INSUFFICIENT, "batch: packed streams exceed the staging buffer (overlapping output slots?)");
     HIPCHK(c->h_stage.reserve((size_t)packed + 16));
     HIPCHK(hipMemcpyAsync(c->h_stage.p, c->d_pack.p, (size_t)packed, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -619,20 +700,13 @@ static void matrix_tables(const uint8_t* m5, uint8_t* codes, uint8_t* basesof) {
     }
 }
 
-static int upload_small(cramgpu_ctx* c, const void* src, size_t bytes, hipStream_t s) {
-    // synchronous with respect to the host buffer: small tables only
-    HIPCHK(c->d_small.reserve(bytes));
-    HIPCHK(hipMemcpyAsync(c->d_small.p, src, bytes, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return 0;
-}
-
 int64_t cramgpu_extract_features_dev(cramgpu_ctx* c, const cramgpu_reads* reads, const uint8_t* d_ref,
                                      cramgpu_features* feats, int64_t* d_sub_hist, void* stream) {
     if (!c || !reads || !feats || reads->n_reads < 0 || !feats->off) return fail(CRAMGPU_E_ARG, "extract_features: bad argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
     const int32_t n = reads->n_reads;
     HIPCHK(c->d_counts.reserve((size_t)n + 1));
     HIPCHK(c->d_list.reserve((size_t)n + 1));  // reads that have features + (last word) their number
@@ -655,15 +729,16 @@ int32_t cramgpu_assign_codes_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t*
     if (!c || !feats || !matrices || n_reads < 0 || n_cont < 1) return fail(CRAMGPU_E_ARG, "assign_codes: bad argument");
     if (n_reads == 0) return 0;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
     std::vector<uint8_t> codes((size_t)n_cont * 5 * 256), tmp(20);
     for (int i = 0; i < n_cont; i++) matrix_tables(matrices + 5 * i, codes.data() + (size_t)i * 5 * 256, tmp.data());
-    int rc = upload_small(c, codes.data(), codes.size(), s);
-    if (rc) return rc;
-    HIPCHK(launch_assign_codes(n_reads, d_read_cont, feats->off, feats->op, feats->a, c->d_small.p, s));
-    HIPCHK(hipStreamSynchronize(s));  // d_small is reused by the next call
-    return 0;
+    uint8_t* d_codes;
+    SmallSlot* slot;
+    if (int rc = stage_small(c, codes.data(), codes.size(), s, &d_codes, &slot)) return rc;
+    HIPCHK(launch_assign_codes(n_reads, d_read_cont, feats->off, feats->op, feats->a, d_codes, s));
+    return release_small(slot, s);
 }
 
 int32_t cramgpu_matrices_assign_codes_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_cont, int32_t n_cont,
@@ -672,31 +747,35 @@ int32_t cramgpu_matrices_assign_codes_dev(cramgpu_ctx* c, int32_t n_reads, const
     if (!c || !feats || !d_sub_hist || !d_matrices || n_reads < 0 || n_cont < 1)
         return fail(CRAMGPU_E_ARG, "matrices_assign_codes: bad argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
     HIPCHK(c->d_codes25.reserve((size_t)n_cont * 25));
     HIPCHK(launch_matrices_and_codes(d_sub_hist, n_cont, d_matrices, c->d_codes25.p, n_reads, d_read_cont, feats->off, feats->op,
-                                     feats->a, pick(c, stream)));
+                                     feats->a, s));
     return 0;
 }
 
 int32_t cramgpu_restore_bases_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_len, const int32_t* d_aln_start,
                                   const uint8_t* d_rflags, const int32_t* d_read_cont, int32_t n_cont,
                                   const cramgpu_refwin* d_wins, const cramgpu_features* feats, const uint8_t* d_seq,
-                                  const int64_t* d_seq_off, const uint8_t* d_ref, const uint8_t* matrices, uint8_t* d_out,
-                                  const int64_t* d_out_off, int32_t* d_status, void* stream) {
-    if (!c || !feats || !matrices || n_reads < 0 || n_cont < 1) return fail(CRAMGPU_E_ARG, "restore_bases: bad argument");
+                                  const int64_t* d_seq_off, int64_t seq_bytes, const uint8_t* d_ref, const uint8_t* matrices,
+                                  uint8_t* d_out, const int64_t* d_out_off, int32_t* d_status, void* stream) {
+    if (!c || !feats || !matrices || n_reads < 0 || n_cont < 1 || seq_bytes < 0)
+        return fail(CRAMGPU_E_ARG, "restore_bases: bad argument");
     if (n_reads == 0) return 0;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
     std::vector<uint8_t> basesof((size_t)n_cont * 20), tmp(5 * 256);
     for (int i = 0; i < n_cont; i++) matrix_tables(matrices + 5 * i, tmp.data(), basesof.data() + (size_t)i * 20);
-    int rc = upload_small(c, basesof.data(), basesof.size(), s);
-    if (rc) return rc;
+    uint8_t* d_basesof;
+    SmallSlot* slot;
+    if (int rc = stage_small(c, basesof.data(), basesof.size(), s, &d_basesof, &slot)) return rc;
     HIPCHK(launch_restore_bases(n_reads, d_read_len, d_aln_start, d_rflags, d_read_cont, d_wins, *feats, d_seq, d_seq_off,
-                                d_ref, c->d_small.p, d_out, d_out_off, d_status, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return 0;
+                                seq_bytes, d_ref, d_basesof, d_out, d_out_off, d_status, s));
+    return release_small(slot, s);
 }
 
 int32_t cramgpu_restore_quals_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_len, const uint8_t* d_rflags,
@@ -705,9 +784,10 @@ int32_t cramgpu_restore_quals_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t
     if (!c || !feats || n_reads < 0) return fail(CRAMGPU_E_ARG, "restore_quals: bad argument");
     if (n_reads == 0) return 0;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(launch_restore_quals(n_reads, d_read_len, d_rflags, *feats, default_qs, d_scores, d_out_off, d_status,
-                                pick(c, stream)));
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(launch_restore_quals(n_reads, d_read_len, d_rflags, *feats, default_qs, d_scores, d_out_off, d_status, s));
     return 0;
 }
 
@@ -771,6 +851,25 @@ int32_t cramgpu_parse_policies(const char* spec, cramgpu_policy* out, int32_t ma
     return (int32_t)pols.size();
 }
 
+// The pile-up selectors X<n> (LOWER_COVERAGE) and P<n> (PILEUP) read the coverage / mismatch tracks that
+// CramSerilization.updateTracks (src/main/java/htsjdk/samtools/cram/CramSerilization.java:114-128, 225-257) fills before
+// the per-record loop.  This library does not build those tracks (out of scope), so it refuses
+// every term whose result could depend on them instead of silently answering with all-zero tracks.  Accepted are the
+// terms that select nothing whatever the tracks hold: X<n> with n <= 0 (coverage < n is never true) and P<n> with
+// n >= 9999 (more than n mismatching reads on one position; P9999 is the no-op the survey recommends to make the Java
+// CLI create its ReferenceTracks).
+static int policies_supported(const cramgpu_policy* pol, int32_t n_pol) {
+    for (int32_t k = 0; k < n_pol; k++)
+        for (int32_t i = 0; i < pol[k].n_base_cat && i < 8; i++) {
+            const int cat = pol[k].base_cat[i], prm = pol[k].base_param[i];
+            if ((cat == 5 && prm > 0) || (cat == 4 && prm < 9999))
+                return fail(CRAMGPU_E_UNSUPPORTED,
+                            "lossy model: X<n> / P<n> terms need the coverage and mismatch tracks of CramSerilization.updateTracks, "
+                            "which this library does not build (only the no-ops X0 and P>=9999 are accepted)");
+        }
+    return 0;
+}
+
 static bool host_read_gate(const cramgpu_policy& p, bool unmapped, int mapq) {
     switch (p.read_cat) {
         case 0: case 4: return true;
@@ -784,7 +883,9 @@ static bool host_read_gate(const cramgpu_policy& p, bool unmapped, int mapq) {
 // ReferenceTracks.ensureRange :127-133 / moveForwardTo :87-119 replayed in read order
 int32_t cramgpu_tracks_windows(int32_t n_reads, const int32_t* aln_start, const int32_t* aln_span, const uint8_t* rflags,
                                const uint8_t* mapq, const cramgpu_policy* pol, int32_t n_pol, int64_t ref_len,
-                               int32_t window, int32_t* wpos) {
+                               int32_t window, int32_t* wpos, int32_t* throws_at) {
+    if (throws_at) *throws_at = -1;
+    if (int rc = policies_supported(pol, n_pol)) return rc;
     const int64_t W = window < ref_len ? window : ref_len;
     int64_t position = 1;
     for (int32_t r = 0; r < n_reads; r++) {
@@ -795,10 +896,14 @@ int32_t cramgpu_tracks_windows(int32_t n_reads, const int32_t* aln_start, const 
             if (pol[k].n_base_cat > 0 && host_read_gate(pol[k], (rflags[r] & CRAMGPU_RF_UNMAPPED) != 0, mapq[r])) need = true;
         if (!need || aln_start[r] == 0) continue;
         const int64_t start = aln_start[r];
-        if (start < position) return -(r + 1);
+        auto throws = [&]() {
+            if (throws_at) *throws_at = r;
+            return fail(CRAMGPU_E_JAVA_THROWS, "ReferenceTracks would throw (reads not sorted by start, or a start beyond the contig)");
+        };
+        if (start < position) return throws();
         if (start + aln_span[r] > position + W) {
             int64_t np = start;
-            if (np - 1 >= ref_len) return -(r + 1);
+            if (np - 1 >= ref_len) return throws();
             if (np > ref_len - W + 1) np = ref_len - W + 1;
             position = np;
         }
@@ -811,21 +916,25 @@ int32_t cramgpu_lossy_quals_dev(cramgpu_ctx* c, const cramgpu_reads* reads, cons
                                 int32_t window, const cramgpu_policy* pol, int32_t n_pol, uint8_t* d_scores,
                                 uint8_t* d_force, int32_t* d_status, void* stream) {
     if (!c || !reads || n_pol < 0 || (n_pol > 0 && !pol)) return fail(CRAMGPU_E_ARG, "lossy_quals: bad argument");
+    if (int rc = policies_supported(pol, n_pol)) return rc;
     if (reads->n_reads == 0) return 0;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
     cramgpu_policy dummy{};
-    int rc = upload_small(c, n_pol ? (const void*)pol : (const void*)&dummy, sizeof(cramgpu_policy) * (size_t)std::max(n_pol, 1), s);
-    if (rc) return rc;
+    uint8_t* d_pol;
+    SmallSlot* slot;
+    if (int rc = stage_small(c, n_pol ? (const void*)pol : (const void*)&dummy, sizeof(cramgpu_policy) * (size_t)std::max(n_pol, 1), s,
+                             &d_pol, &slot))
+        return rc;
     // global mask scratch for reads longer than the LDS mask (sized by the caller-visible arena: not known here, so
     // it is sized from the largest base offset + length, read back once)
     if (reads->max_read_len < 0 || reads->n_bases < 0) return fail(CRAMGPU_E_ARG, "lossy_quals: n_bases / max_read_len unset");
     HIPCHK(c->d_maskws.reserve(reads->max_read_len + 1 > 16384 ? (size_t)reads->n_bases + (size_t)reads->n_reads + 64 : 64));
-    HIPCHK(launch_lossy_quals(*reads, d_ref, d_wpos, window, (const cramgpu_policy*)c->d_small.p, n_pol, d_scores, d_force,
+    HIPCHK(launch_lossy_quals(*reads, d_ref, d_wpos, window, (const cramgpu_policy*)d_pol, n_pol, d_scores, d_force,
                               d_status, c->d_maskws.p, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return 0;
+    return release_small(slot, s);
 }
 
 int64_t cramgpu_merge_quality_features_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_len,
@@ -834,8 +943,9 @@ int64_t cramgpu_merge_quality_features_dev(cramgpu_ctx* c, int32_t n_reads, cons
                                            void* stream) {
     if (!c || !in || !out || n_reads < 0 || !out->off) return fail(CRAMGPU_E_ARG, "merge_quality_features: bad argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
     HIPCHK(c->d_counts.reserve((size_t)n_reads + 1));
     if (n_reads > 0)
         HIPCHK(launch_merge_quality(n_reads, d_read_len, d_base_off, d_scores, d_force, d_qstatus, *in, *out, c->d_counts.p,

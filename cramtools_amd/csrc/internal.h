@@ -56,6 +56,7 @@ hipError_t launch_gather(const uint8_t* src, const int64_t* pos, const int32_t* 
                          hipStream_t s);
 
 // record kernels
+void records_set_cu_count(int n_cu);  // grid sizing of the record kernels
 hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
                                    int32_t* d_counts, bool write_pass, int32_t* list, uint32_t* list_n, hipStream_t s);
 size_t feature_scan_ws_elems(int32_t n_reads);  // int64 elements of workspace launch_feature_scan needs
@@ -67,8 +68,8 @@ hipError_t launch_matrices_and_codes(const int64_t* d_hist, int32_t n_cont, uint
                                      const int32_t* read_cont, const int64_t* off, const uint8_t* op, int32_t* a, hipStream_t s);
 hipError_t launch_restore_bases(int32_t n_reads, const int32_t* read_len, const int32_t* aln_start, const uint8_t* rflags,
                                 const int32_t* read_cont, const cramgpu_refwin* wins, cramgpu_features f,
-                                const uint8_t* seq, const int64_t* seq_off, const uint8_t* ref, const uint8_t* d_basesof,
-                                uint8_t* out, const int64_t* out_off, int32_t* status, hipStream_t s);
+                                const uint8_t* seq, const int64_t* seq_off, int64_t seq_bytes, const uint8_t* ref,
+                                const uint8_t* d_basesof, uint8_t* out, const int64_t* out_off, int32_t* status, hipStream_t s);
 hipError_t launch_restore_quals(int32_t n_reads, const int32_t* read_len, const uint8_t* rflags, cramgpu_features f,
                                 uint8_t default_qs, uint8_t* scores, const int64_t* out_off, int32_t* status,
                                 hipStream_t s);

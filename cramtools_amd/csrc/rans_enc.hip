@@ -15,7 +15,7 @@
 // from a ticket counter:
 //   wave 1 ("helper")  1. histograms the input (LDS counters, lane-replicated for small alphabets),
 //                      2. normalises, serialises the frequency table, builds packed encoder symbols (a row per lane),
-//                      3. per batch of 16 coding steps: fetches the 64 symbol/context bytes, looks the symbols up and
+//                      3. per batch of 32 coding steps (two halves of 16): fetches the symbol/context bytes, looks the symbols up and
 //                         expands them into a 16-byte record per (step, state) in an LDS staging buffer; turns the
 //                         states the chain logged for the previous batch into output bytes, placed with a
 //                         ballot/popcount prefix in the reference's emission order (state 3,2,1,0 per step) and
@@ -930,7 +930,6 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
             if (i < nbatch && l < 4) {
 #pragma unroll
                 for (int h = 0; h < kHalves; h++) {
-                    // the flag word is read on its own, first: waiting for it does not wait for the sixteen records
                     // the flag is read first and from its own word: waiting for it does not wait for the sixteen records
                     const uint32_t fw = L->p3.gflag[buf][h];
                     uint4 P[kSteps];

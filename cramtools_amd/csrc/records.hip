@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void restore_bases_kernel(int32_t n_reads, con
                                                             const int32_t* aln_start, const uint8_t* rflags,
                                                             const int32_t* read_cont, const cramgpu_refwin* wins,
                                                             cramgpu_features F, const uint8_t* seq, const int64_t* seq_off,
-                                                            const uint8_t* ref, const uint8_t* basesof, uint8_t* out,
+                                                            int64_t seq_bytes, const uint8_t* ref, const uint8_t* basesof, uint8_t* out,
                                                             const int64_t* out_off, int32_t* status) {
     const int lane = threadIdx.x & 63;
     const int n_waves = wave_count();
@@ -601,11 +601,13 @@ __global__ __launch_bounds__(256) void restore_bases_kernel(int32_t n_reads, con
                         pir++;
                         pis++;
                     } else if (opc == 'I' || opc == 'S') {
-                        if (fbv < 0 || pir - 1 + fbv > L) {
+                        // the sequence bytes must lie inside the seq arena (Java: the feature owns its byte[])
+                        const int64_t so = seq_off[r] + fa;
+                        if (fbv < 0 || pir - 1 + fbv > L || fa < 0 || so < 0 || so + fbv > seq_bytes) {
                             bad = true;
                             break;
                         }
-                        const uint8_t* s = seq + seq_off[r] + fa;
+                        const uint8_t* s = seq + so;
                         for (int i = lane; i < fbv; i += 64) b[pir - 1 + i] = normalize_base(s[i]);
                         pir += fbv;
                     } else if (opc == 'D' || opc == 'N') {
@@ -677,18 +679,20 @@ __global__ __launch_bounds__(256) void restore_quals_kernel(int32_t n_reads, con
                 for (int i = lane; i < L; i += 64) s[i] = default_qs;
                 __threadfence_block();
                 __builtin_amdgcn_wave_barrier();
-                bool any = false;
+                bool any = false, bad = false;
                 for (int64_t f = F.off[r] + lane; f < F.off[r + 1]; f += 64) {
                     const int opc = F.op[f];
-                    if (opc == 'Q') {
-                        s[F.pos[f] - 1] = (uint8_t)F.a[f];
-                        any = true;
-                    } else if (opc == 'B') {
-                        s[F.pos[f] - 1] = (uint8_t)F.b[f];
-                        any = true;
+                    if (opc == 'Q' || opc == 'B') {
+                        const int p = F.pos[f];
+                        if (p < 1 || p > L) {  // :302 / :307 scores[pos - 1] throws ArrayIndexOutOfBounds
+                            bad = true;
+                        } else {
+                            s[p - 1] = (uint8_t)(opc == 'Q' ? F.a[f] : F.b[f]);
+                            any = true;
+                        }
                     }
                 }
-                st = __ballot(any) ? 0 : 1;
+                st = __ballot(bad) ? CRAMGPU_E_JAVA_THROWS : __ballot(any) ? 0 : 1;
             } else {
                 int missing = 0;
                 for (int i = lane; i < L; i += 64) {
@@ -728,8 +732,8 @@ __global__ __launch_bounds__(256) void restore_bases_lane_kernel(int32_t n_reads
                                                                  const int32_t* aln_start, const uint8_t* rflags,
                                                                  const int32_t* read_cont, const cramgpu_refwin* wins,
                                                                  cramgpu_features F, const uint8_t* seq,
-                                                                 const int64_t* seq_off, const uint8_t* ref,
-                                                                 const uint8_t* basesof, uint8_t* out,
+                                                                 const int64_t* seq_off, int64_t seq_bytes,
+                                                                 const uint8_t* ref, const uint8_t* basesof, uint8_t* out,
                                                                  const int64_t* out_off, int32_t* status) {
     const int stride = (int)(gridDim.x * blockDim.x);
     for (int r = (int)(blockIdx.x * blockDim.x + threadIdx.x); r < n_reads; r += stride) {
@@ -794,11 +798,13 @@ __global__ __launch_bounds__(256) void restore_bases_lane_kernel(int32_t n_reads
                         pir++;
                         pis++;
                     } else if (opc == 'I' || opc == 'S') {
-                        if (fbv < 0 || pir - 1 + fbv > L) {
+                        // the sequence bytes must lie inside the seq arena (Java: the feature owns its byte[])
+                        const int64_t so = seq_off[r] + fa;
+                        if (fbv < 0 || pir - 1 + fbv > L || fa < 0 || so < 0 || so + fbv > seq_bytes) {
                             bad = true;
                             break;
                         }
-                        const uint8_t* s = seq + seq_off[r] + fa;
+                        const uint8_t* s = seq + so;
                         for (int i = 0; i < fbv; i++) b[pir - 1 + i] = normalize_base(s[i]);
                         pir += fbv;
                     } else if (opc == 'D' || opc == 'N') {
@@ -894,18 +900,20 @@ __global__ __launch_bounds__(256) void restore_quals_lane_kernel(int32_t n_reads
                 int i = 0;
                 for (; i + 16 <= L; i += 16) *reinterpret_cast<PackedU32x4*>(s + i) = PackedU32x4{{dq4, dq4, dq4, dq4}};
                 for (; i < L; i++) s[i] = default_qs;
-                bool any = false;
+                bool any = false, bad = false;
                 for (int64_t f = F.off[r]; f < F.off[r + 1]; f++) {
                     const int opc = F.op[f];
-                    if (opc == 'Q') {
-                        s[F.pos[f] - 1] = (uint8_t)F.a[f];
-                        any = true;
-                    } else if (opc == 'B') {
-                        s[F.pos[f] - 1] = (uint8_t)F.b[f];
-                        any = true;
+                    if (opc == 'Q' || opc == 'B') {
+                        const int p = F.pos[f];
+                        if (p < 1 || p > L) {  // :302 / :307 scores[pos - 1] throws ArrayIndexOutOfBounds
+                            bad = true;
+                        } else {
+                            s[p - 1] = (uint8_t)(opc == 'Q' ? F.a[f] : F.b[f]);
+                            any = true;
+                        }
                     }
                 }
-                st = any ? 0 : 1;
+                st = bad ? CRAMGPU_E_JAVA_THROWS : any ? 0 : 1;
             } else {
                 int missing = 0, i = 0;
                 for (; i + 16 <= L; i += 16) {
@@ -1158,19 +1166,25 @@ __global__ void merge_quality_kernel(int32_t n_reads, const int32_t* read_len, c
 
 }  // namespace
 
+// CU count of the device the launches go to (set by cramgpu_open from hipDeviceProp_t; every MI355X has 256)
+static int g_n_cu = 256;
+void records_set_cu_count(int n_cu) {
+    if (n_cu > 0) g_n_cu = n_cu;
+}
+
 static int lane_grid(int64_t n_reads) {  // a lane per read, grid-stride beyond the resident workgroups
     static const int per_cu = [] {
         const char* e = getenv("CRAMGPU_LANE_WGS_PER_CU");
         const int v = e ? atoi(e) : 0;
         return v > 0 && v <= 64 ? v : 32;
     }();
-    const int64_t blocks = (n_reads + 255) / 256, cap = 256 * (int64_t)per_cu;
+    const int64_t blocks = (n_reads + 255) / 256, cap = g_n_cu * (int64_t)per_cu;
     return (int)(blocks < 1 ? 1 : blocks > cap ? cap : blocks);
 }
 static int grid_for_waves(int64_t n_items, int waves_per_block) {
     int64_t blocks = (n_items + waves_per_block - 1) / waves_per_block;
     if (blocks < 1) blocks = 1;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > g_n_cu * 16) blocks = g_n_cu * 16;
     return (int)blocks;
 }
 
@@ -1231,13 +1245,13 @@ hipError_t launch_matrices_and_codes(const int64_t* d_hist, int32_t n_cont, uint
 
 hipError_t launch_restore_bases(int32_t n_reads, const int32_t* read_len, const int32_t* aln_start, const uint8_t* rflags,
                                 const int32_t* read_cont, const cramgpu_refwin* wins, cramgpu_features f,
-                                const uint8_t* seq, const int64_t* seq_off, const uint8_t* ref, const uint8_t* d_basesof,
-                                uint8_t* out, const int64_t* out_off, int32_t* status, hipStream_t s) {
+                                const uint8_t* seq, const int64_t* seq_off, int64_t seq_bytes, const uint8_t* ref,
+                                const uint8_t* d_basesof, uint8_t* out, const int64_t* out_off, int32_t* status, hipStream_t s) {
     // reads up to kLaneReadMax bases: a lane each; longer ones: a wave each (found 64 reads at a time)
     hipLaunchKernelGGL(restore_bases_lane_kernel, dim3(lane_grid(n_reads)), dim3(256), 0, s, n_reads, read_len, aln_start,
-                       rflags, read_cont, wins, f, seq, seq_off, ref, d_basesof, out, out_off, status);
+                       rflags, read_cont, wins, f, seq, seq_off, seq_bytes, ref, d_basesof, out, out_off, status);
     hipLaunchKernelGGL(restore_bases_kernel, dim3(grid_for_waves(((int64_t)n_reads + 63) / 64, 4)), dim3(256), 0, s, n_reads, read_len,
-                       aln_start, rflags, read_cont, wins, f, seq, seq_off, ref, d_basesof, out, out_off, status);
+                       aln_start, rflags, read_cont, wins, f, seq, seq_off, seq_bytes, ref, d_basesof, out, out_off, status);
     return hipGetLastError();
 }
 
@@ -1254,7 +1268,7 @@ hipError_t launch_restore_quals(int32_t n_reads, const int32_t* read_len, const 
 hipError_t launch_lossy_quals(const cramgpu_reads& r, const uint8_t* ref, const int32_t* wpos, int32_t window,
                               const cramgpu_policy* d_pol, int32_t n_pol, uint8_t* scores, uint8_t* force,
                               int32_t* status, uint8_t* d_mask_ws, hipStream_t s) {
-    int grid = r.n_reads < 256 * 8 ? (r.n_reads > 0 ? r.n_reads : 1) : 256 * 8;
+    int grid = r.n_reads < g_n_cu * 8 ? (r.n_reads > 0 ? r.n_reads : 1) : g_n_cu * 8;
     hipLaunchKernelGGL(lossy_quals_kernel, dim3(grid), dim3(64), 0, s, r, ref, wpos, window, d_pol, n_pol, scores, force,
                        status, d_mask_ws);
     return hipGetLastError();

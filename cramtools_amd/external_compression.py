@@ -26,7 +26,7 @@ def rans_bound(n):
 def rans(data, order):
     """ExternalCompression.rans(byte[] data, int order) -> bytes."""
     if order not in (0, 1):
-        raise CramGpuError(_lib.E_ORDER, "Unknown rANS order: %r" % (order,))
+        raise CramGpuError(_lib.E_ORDER, arg=order)  # RANS.ORDER.fromInt: "Unknown rANS order: X"
     d = np.frombuffer(bytes(data), np.uint8)
     if d.size == 0:
         return b""
@@ -44,7 +44,10 @@ def unrans(data):
         return b""
     raw = _lib.check(_lib.lib().cramgpu_rans_raw_size(d.ctypes.data, d.size))
     out = np.empty(max(raw, 1), np.uint8)
-    r = _lib.check(_lib.lib().cramgpu_rans_uncompress(d.ctypes.data, d.size, out.ctypes.data, raw))
+    r = _lib.lib().cramgpu_rans_uncompress(d.ctypes.data, d.size, out.ctypes.data, raw)
+    if r == _lib.E_OUT_TOO_SMALL:  # RANS#uncompress: "Output buffer too small to fit N bytes."
+        raise CramGpuError(r, arg=raw)
+    _lib.check(r)
     return out[:r].tobytes()
 
 

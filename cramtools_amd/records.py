@@ -228,7 +228,8 @@ class CramNormalizer:
         fs = feats.struct()
         _lib.check(_lib.lib().cramgpu_restore_bases_dev(
             self.engine.handle, n, rl.data_ptr(), st.data_ptr(), fl.data_ptr(), rc.data_ptr() if rc is not None else None,
-            w.shape[0], d_win.data_ptr(), C.byref(fs), d_seq.data_ptr(), d_seq_off.data_ptr(), d_ref.data_ptr(),
+            w.shape[0], d_win.data_ptr(), C.byref(fs), d_seq.data_ptr(), d_seq_off.data_ptr(), int(d_seq.numel()),
+            d_ref.data_ptr(),
             m.ctypes.data, out.data_ptr(), out_off.data_ptr(), status.data_ptr(), _stream()))
         torch.cuda.synchronize()
         return out, out_off, status[:n]
@@ -274,11 +275,14 @@ class QualityScorePreservation:
         fl = np.ascontiguousarray(rflags, np.uint8)
         mq = np.ascontiguousarray(mapq, np.uint8)
         wpos = np.zeros(max(n, 1), np.int32)
+        at = C.c_int32(-1)
         r = _lib.lib().cramgpu_tracks_windows(n, a.ctypes.data, sp.ctypes.data, fl.ctypes.data, mq.ctypes.data,
                                               self.policies, self.n_pol, int(ref_len),
-                                              int(window if window is not None else self.WINDOW), wpos.ctypes.data)
-        if r < 0:
-            raise CramGpuError(_lib.E_JAVA_THROWS, "ReferenceTracks would throw at read %d" % (-r - 1))
+                                              int(window if window is not None else self.WINDOW), wpos.ctypes.data,
+                                              C.byref(at))
+        if r == _lib.E_JAVA_THROWS:
+            raise CramGpuError(r, "ReferenceTracks would throw at read %d" % at.value)
+        _lib.check(r)
         return wpos[:n]
 
     def add_quality_scores(self, reads, d_ref, wpos, window=None):

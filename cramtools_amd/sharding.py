@@ -23,14 +23,18 @@ class OrderingBuffer:
         self._heap = []
         self._lock = threading.Lock()
 
-    def put(self, ordinal, payload):
-        """Returns the list of payloads that became releasable, in order."""
+    def put(self, ordinal, payload, sink=None):
+        """Returns the list of payloads that became releasable, in order.  `sink(list)` is called with that list while
+        the buffer's lock is still held, so that concurrent producers hand their releases on in ordinal order too
+        (two workers each holding a released batch could otherwise append them in either order)."""
         with self._lock:
             heapq.heappush(self._heap, (ordinal, id(payload), payload))
             out = []
             while self._heap and self._heap[0][0] == self._next:
                 out.append(heapq.heappop(self._heap)[2])
                 self._next += 1
+            if sink is not None and out:
+                sink(out)
             return out
 
     def pending(self):
@@ -49,7 +53,6 @@ class ContainerQueue:
         self._jobs = [[] for _ in self.engines]
         self._order = OrderingBuffer()
         self._out = []
-        self._out_lock = threading.Lock()
         self._err = None
 
     def submit(self, ordinal, job):
@@ -59,10 +62,7 @@ class ContainerQueue:
         try:
             for ordinal, job in self._jobs[g]:
                 res = self.engines[g].run(job)
-                ready = self._order.put(ordinal, (ordinal, res))
-                if ready:
-                    with self._out_lock:
-                        self._out.extend(ready)
+                self._order.put(ordinal, (ordinal, res), sink=self._out.extend)
         except Exception as e:  # CRAMContainerAsynchWriter.exceptionInWorker: remember, rethrow to the caller
             self._err = e
 
@@ -78,6 +78,21 @@ class ContainerQueue:
         if self._order.pending():
             raise RuntimeError("container ordinals are not contiguous from 0")
         return self._out
+
+
+class EngineCoder:
+    """`.run(job)` adapter of one `external_compression.Engine` (= one GPU) for `ContainerQueue`: a job is the external
+    blocks of one container, `(datas, orders)` to encode or `(streams, None)` to decode, as
+    `BamToCram_OBA_Function.apply` / `CramToBam_OBA_Function.apply` see them (paralell/*.java)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def run(self, job):
+        items, orders = job
+        if orders is None:
+            return self.engine.uncompress_many(items)
+        return self.engine.compress_many(items, orders)
 
 
 def timed_region(fn, steps, dist=None, sync=None):

@@ -12,7 +12,12 @@
  *   - stream arguments are hipStream_t passed as void* (NULL = HIP's null stream, i.e. torch's default stream).
  *   - functions return >= 0 on success and a negative CRAMGPU_E_* code on failure; per-block results of
  *     batch calls carry the same codes in out_len[].
- *   - all functions are thread-safe on distinct contexts; one context serialises its calls internally.
+ *   - all functions are thread-safe on distinct contexts; one context serialises its calls internally: on the host
+ *     by a mutex, on the device by an event (consecutive calls on DIFFERENT streams of one context are ordered one
+ *     behind the other, because they share the context's scratch; calls on one stream are stream-ordered anyway).
+ *     Use one context per stream that should run concurrently.
+ *   - the level-0 functions share ONE process-wide context on device 0: concurrent callers (TransformerJob threads)
+ *     serialise on it.  They are the day-one shim; a converter thread that wants overlap uses level 1.
  */
 #ifndef CRAMGPU_H
 #define CRAMGPU_H
@@ -35,6 +40,7 @@ extern "C" {
 #define CRAMGPU_E_HIP (-7)            /* a HIP runtime call failed; cramgpu_last_error() has the text */
 #define CRAMGPU_E_NO_DEVICE (-8)      /* no gfx950 device visible: the library never falls back to a CPU path */
 #define CRAMGPU_E_JAVA_THROWS (-9)    /* record kernels: the reference would throw (index out of range, NPE) */
+#define CRAMGPU_E_UNSUPPORTED (-10)   /* a lossy-model term that needs ReferenceTracks' coverage / mismatch tracks */
 
 #define CRAMGPU_ARENA_ALIGN 16        /* every block / stream offset inside a device arena is a multiple of this */
 
@@ -105,7 +111,9 @@ int32_t cramgpu_rans_decode_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* 
  * `align` bytes, a power of two >= 1) into d_dst, writes the start offsets to d_dst_off (int64[n+1], device).
  * max_len = an upper bound of every d_len[b] (e.g. the largest out_cap).
  * Used to shrink the encode output before the D2H copy.  No reference counterpart (Java's toByteArray L146-150
- * is the per-block analogue). */
+ * is the per-block analogue).  d_dst_off is always complete; when the packed size d_dst_off[n] exceeds dst_cap NOTHING
+ * is copied (the call is stream-ordered and cannot report it): size d_dst for the sum of the rounded-up lengths, or
+ * check d_dst_off[n] <= dst_cap before reading d_dst. */
 int32_t cramgpu_gather_dev(cramgpu_ctx* ctx, const uint8_t* d_src, const int64_t* d_pos, const int32_t* d_len,
                            int32_t n, int32_t max_len, int32_t align, uint8_t* d_dst, int64_t dst_cap,
                            int64_t* d_dst_off, void* stream);
@@ -214,7 +222,8 @@ int64_t cramgpu_extract_features_dev(cramgpu_ctx* ctx, const cramgpu_reads* read
 void cramgpu_substitution_matrix(const int64_t* sub_hist, uint8_t* matrix5);
 
 /* htsjdk!encoding/writer/Writer#write (L139-261) picks matrix.code(ref, base) for each Substitution: fills bits 16..23
- * of a[] for every X feature.  matrices = HOST array of n_cont x 5 header bytes; d_read_cont as in cramgpu_reads. */
+ * of a[] for every X feature.  matrices = HOST array of n_cont x 5 header bytes (copied before the call returns);
+ * d_read_cont as in cramgpu_reads.  Stream-ordered, does not synchronise. */
 int32_t cramgpu_assign_codes_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32_t* d_read_cont, int32_t n_cont,
                                  const cramgpu_features* feats, const uint8_t* matrices, void* stream);
 
@@ -229,16 +238,20 @@ int32_t cramgpu_matrices_assign_codes_dev(cramgpu_ctx* ctx, int32_t n_reads, con
 
 /* K4 / N1 — src/main/java/htsjdk/samtools/cram/build/CramNormalizer.java:335-441 (restoreReadBases), called from
  * :137 and :239 with a ReferenceRegion window (d_wins[n_cont] into d_ref).  matrices = HOST n_cont x 5 bytes.
- * d_seq/d_seq_off: bytes of S / I features (feature a = offset relative to d_seq_off[r]).
- * d_status[r]: 0 bases written, 1 NULL_SEQUENCE, 2 skipped, CRAMGPU_E_JAVA_THROWS. */
+ * d_seq/d_seq_off: bytes of S / I features (feature a = offset relative to d_seq_off[r]); seq_bytes = size of d_seq:
+ * a feature whose bytes would lie outside [0, seq_bytes) gives its read CRAMGPU_E_JAVA_THROWS.
+ * d_status[r]: 0 bases written, 1 NULL_SEQUENCE, 2 skipped, CRAMGPU_E_JAVA_THROWS (a feature position outside the
+ * read, a window the read starts in front of: the reference raises an index exception there).
+ * Stream-ordered, does not synchronise (the matrices are copied before the call returns). */
 int32_t cramgpu_restore_bases_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32_t* d_read_len, const int32_t* d_aln_start,
                                   const uint8_t* d_rflags, const int32_t* d_read_cont, int32_t n_cont,
                                   const cramgpu_refwin* d_wins, const cramgpu_features* feats, const uint8_t* d_seq,
-                                  const int64_t* d_seq_off, const uint8_t* d_ref, const uint8_t* matrices, uint8_t* d_out,
-                                  const int64_t* d_out_off, int32_t* d_status, void* stream);
+                                  const int64_t* d_seq_off, int64_t seq_bytes, const uint8_t* d_ref, const uint8_t* matrices,
+                                  uint8_t* d_out, const int64_t* d_out_off, int32_t* d_status, void* stream);
 
 /* N2 — CramNormalizer.java:287-333 (restoreQualityScores; default score 30 = '?'-'!', :141,:204).
- * d_scores is in/out at d_out_off[r]; d_status[r]: 0 valid, 1 NULL_QUALS, 2 skipped. */
+ * d_scores is in/out at d_out_off[r]; d_status[r]: 0 valid, 1 NULL_QUALS, 2 skipped, CRAMGPU_E_JAVA_THROWS (a Q or B
+ * feature whose position lies outside [1, read_len]: CramNormalizer.java:302,307 index scores[pos - 1]). */
 int32_t cramgpu_restore_quals_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32_t* d_read_len, const uint8_t* d_rflags,
                                   const cramgpu_features* feats, uint8_t default_qs, uint8_t* d_scores,
                                   const int64_t* d_out_off, int32_t* d_status, void* stream);
@@ -260,7 +273,10 @@ typedef struct {
 int32_t cramgpu_parse_policies(const char* spec, cramgpu_policy* out, int32_t max_pol);
 
 /* K5 / Q2 — QualityScorePreservation.addQualityScores :276-301, addQS :332-489, applyTreatment :263-274,
- * lossy/Binning.java:63-71, ref/ReferenceTracks.java:127-155 (baseAt semantics; coverage / mismatch tracks read 0).
+ * lossy/Binning.java:63-71, ref/ReferenceTracks.java:127-155 (baseAt semantics).  The coverage / mismatch tracks of
+ * CramSerilization.updateTracks (CramSerilization.java:114-128, 225-257) are NOT built: a policy with an X<n> (n > 0)
+ * or P<n> (n < 9999) term is refused with CRAMGPU_E_UNSUPPORTED, here and in cramgpu_tracks_windows; the no-op terms X0
+ * and P9999 are accepted.  Stream-ordered, does not synchronise (the policies are copied first).
  * d_wpos[r] = 1-based ReferenceTracks window position in force when read r is processed (ReferenceTracks.java:87-133;
  * sequential host state, computed by cramgpu_tracks_windows); reads->win must cover the whole contig.  pol = HOST array.
  * Outputs: d_scores (0xFF = hole) at base_off[r],
@@ -270,10 +286,11 @@ int32_t cramgpu_lossy_quals_dev(cramgpu_ctx* ctx, const cramgpu_reads* reads, co
                                 uint8_t* d_scores, uint8_t* d_force, int32_t* d_status, void* stream);
 
 /* ReferenceTracks.ensureRange / moveForwardTo (ReferenceTracks.java:87-133) replayed over the reads of a container in
- * order: HOST arrays in, wpos[] out.  Returns 0 or -(r+1) when the reference would throw at read r. */
+ * order: HOST arrays in, wpos[] out.  Returns 0, CRAMGPU_E_JAVA_THROWS when the reference would throw (the read's
+ * index goes to *throws_at, which may be NULL), or CRAMGPU_E_UNSUPPORTED (see cramgpu_lossy_quals_dev). */
 int32_t cramgpu_tracks_windows(int32_t n_reads, const int32_t* aln_start, const int32_t* aln_span, const uint8_t* rflags,
                                const uint8_t* mapq, const cramgpu_policy* pol, int32_t n_pol, int64_t ref_len,
-                               int32_t window, int32_t* wpos);
+                               int32_t window, int32_t* wpos, int32_t* throws_at);
 
 /* Tail of addQualityScores (:288-299): appends BaseQualityScore features for non-forced reads and stable-sorts by
  * position.  Returns the merged feature count (synchronises the stream) or a negative code. */

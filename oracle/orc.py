@@ -308,12 +308,19 @@ def restore_quals(read_len, rflags, feats, scores, default_qs=30):
     return sc, status
 
 
-def tracks_windows(reads, pols, ref_len, window=1000000):
+def tracks_windows_rc(reads, pols, ref_len, window=1000000, wpos=None):
+    """Raw return code of orc_tracks_windows: 0, or -(r + 1) when ReferenceTracks would throw at read r."""
     arr = policies_to_c(pols)
+    if wpos is None:
+        wpos = np.zeros(reads.n, np.int32)
+    return lib().orc_tracks_windows(ctypes.c_int32(reads.n), _p(reads.aln_start), _p(reads.aln_span), _p(reads.rflags),
+                                    _p(reads.mapq), arr, ctypes.c_int32(len(pols)), ctypes.c_int64(ref_len),
+                                    ctypes.c_int32(window), _p(wpos))
+
+
+def tracks_windows(reads, pols, ref_len, window=1000000):
     wpos = np.zeros(reads.n, np.int32)
-    r = lib().orc_tracks_windows(ctypes.c_int32(reads.n), _p(reads.aln_start), _p(reads.aln_span), _p(reads.rflags),
-                                 _p(reads.mapq), arr, ctypes.c_int32(len(pols)), ctypes.c_int64(ref_len),
-                                 ctypes.c_int32(window), _p(wpos))
+    r = tracks_windows_rc(reads, pols, ref_len, window, wpos)
     if r < 0:
         raise RuntimeError("ReferenceTracks would throw at read %d" % (-r - 1))
     return wpos

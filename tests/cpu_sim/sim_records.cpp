@@ -198,7 +198,8 @@ int run_container(cramgpu_ctx* ctx, Container& c, int ref_len, int tag) {
         std::vector<int32_t> st(n), ost(n);
         // S features index the read's own bases (encode side); on decode the sequence arena plays that part
         CHECK(cramgpu_restore_bases_dev(ctx, n, c.read_len.data(), c.aln_start.data(), c.rflags.data(), nullptr, 1, &w2, &F,
-                                        c.bases.data(), c.base_off.data(), c.ref.data(), m5, out.data(), out_off.data(),
+                                        c.bases.data(), c.base_off.data(), (int64_t)c.bases.size(), c.ref.data(), m5, out.data(),
+                                        out_off.data(),
                                         st.data(), nullptr) == 0, "restore_bases failed");
         orc_restore_bases(n, c.read_len.data(), c.aln_start.data(), c.rflags.data(), ooff.data(), oop.data(), opos.data(),
                           oa.data(), ob.data(), c.bases.data(), c.base_off.data(), c.ref.data() + lo, hi - lo, lo, om5,
@@ -212,7 +213,20 @@ int run_container(cramgpu_ctx* ctx, Container& c, int ref_len, int tag) {
         }
     }
     // ---- K5 + merge + N2 for several policies ----
-    const char* specs[] = {"N40-D8", "R8-N40-D8", "*8", "N40", "m5", "I40", "R8", "R40-X5", "U8-P3", "M10_0-N8"};
+    // terms that depend on the coverage / mismatch tracks are refused: only the no-ops X0 / P9999 run
+    for (const char* spec : {"R40-X5", "U8-P3"}) {
+        cramgpu_policy pol[16];
+        int np = cramgpu_parse_policies(spec, pol, 16);
+        CHECK(np >= 0, "parse %s failed", spec);
+        std::vector<int32_t> wpos(n + 1);
+        CHECK(cramgpu_tracks_windows(n, c.aln_start.data(), c.aln_span.data(), c.rflags.data(), c.mapq.data(), pol, np, ref_len,
+                                     1000000, wpos.data(), nullptr) == CRAMGPU_E_UNSUPPORTED, "tracks_windows accepted %s", spec);
+        std::vector<uint8_t> sc(c.bases.size() + 1), fr(n + 1);
+        std::vector<int32_t> st(n + 1);
+        CHECK(cramgpu_lossy_quals_dev(ctx, &R, c.ref.data(), wpos.data(), 1000000, pol, np, sc.data(), fr.data(), st.data(),
+                                      nullptr) == CRAMGPU_E_UNSUPPORTED, "lossy_quals accepted %s", spec);
+    }
+    const char* specs[] = {"N40-D8", "R8-N40-D8", "*8", "N40", "m5", "I40", "R8", "R40-X0", "U8-P9999", "M10_0-N8"};
     for (const char* spec : specs) {
         cramgpu_policy pol[16];
         int np = cramgpu_parse_policies(spec, pol, 16);
@@ -220,8 +234,10 @@ int run_container(cramgpu_ctx* ctx, Container& c, int ref_len, int tag) {
         static_assert(sizeof(cramgpu_policy) == sizeof(orc_policy_t), "policy layout");
         std::vector<int32_t> wpos(n), owpos(n);
         for (int window : {1000000, 700}) {
+            int32_t at = -1;
             int rc = cramgpu_tracks_windows(n, c.aln_start.data(), c.aln_span.data(), c.rflags.data(), c.mapq.data(), pol, np,
-                                            ref_len, window, wpos.data());
+                                            ref_len, window, wpos.data(), &at);
+            if (rc == CRAMGPU_E_JAVA_THROWS) rc = -(at + 1);  // the oracle's convention
             int orc = orc_tracks_windows(n, c.aln_start.data(), c.aln_span.data(), c.rflags.data(), c.mapq.data(),
                                          (const orc_policy_t*)pol, np, ref_len, window, owpos.data());
             CHECK(rc == orc, "[%d] tracks_windows rc %d vs %d (%s)", tag, rc, orc, spec);

@@ -33,8 +33,9 @@ def hostsim():
     _lib._lib, _lib.LIB_PATH, torch.cuda.current_stream, torch.cuda.synchronize = saved
 
 
-def test_rans_gpu_test_bodies(hostsim, kat1, orc):
+def test_rans_gpu_test_bodies(hostsim, kat1, orc, monkeypatch):
     import test_rans_gpu as t
+    monkeypatch.setattr(t, "DEV", "cpu")
     from cramtools_amd import external_compression as xc
     eng = xc.Engine(0)
     try:
@@ -43,6 +44,7 @@ def test_rans_gpu_test_bodies(hostsim, kat1, orc):
         t.test_decoder_accepts_oracle_streams(eng, orc)
         t.test_corrupt_streams_do_not_crash(eng, orc)
         t.test_async_jobs(eng, orc)
+        t.test_gather_reports_overflow(eng, orc)
         import test_foreign_streams as tf
         tf.check_library_decodes(xc)  # tables summing to 4096, F = 4096 in both spellings
         # device-arena entry points + gather, as bench.py drives them
@@ -90,6 +92,7 @@ def test_records_gpu_test_bodies(hostsim, katrec, orc, monkeypatch):
         t.test_kat2_features_matrix_restore(katrec, rk)
         t.test_kat4_window_edges(katrec, rk)
         t.test_kat3_lossy(katrec, rk)
+        t.test_malformed_feature_positions(rk)
     finally:
         eng.close()
 

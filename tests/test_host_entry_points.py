@@ -69,7 +69,7 @@ def test_tracks_windows_matches_oracle(orc):
             want = orc.tracks_windows(reads, pols, 5400, window)
             got = np.zeros(n, np.int32)
             rc = _lib.lib().cramgpu_tracks_windows(n, starts.ctypes.data, span.ctypes.data, rflags.ctypes.data,
-                                                   mapq.ctypes.data, arr, npol, 5400, window, got.ctypes.data)
+                                                   mapq.ctypes.data, arr, npol, 5400, window, got.ctypes.data, None)
             assert rc == 0
             assert np.array_equal(got, want), (spec, window)
     # an unsorted container makes ReferenceTracks throw ("Cannot move the window backwards")
@@ -78,8 +78,26 @@ def test_tracks_windows_matches_oracle(orc):
     arr = (_lib.Policy * 32)()
     npol = _lib.lib().cramgpu_parse_policies(b"N40", arr, 32)
     got = np.zeros(n, np.int32)
+    import ctypes
+    at = ctypes.c_int32(-1)
     assert _lib.lib().cramgpu_tracks_windows(n, bad.ctypes.data, span.ctypes.data, rflags.ctypes.data, mapq.ctypes.data,
-                                             arr, npol, 5400, 900, got.ctypes.data) < 0
+                                             arr, npol, 5400, 900, got.ctypes.data, ctypes.byref(at)) == _lib.E_JAVA_THROWS
+    want_rc = orc.tracks_windows_rc(reads_with(bad, reads), orc.parse_policies("N40"), 5400, 900)
+    assert want_rc == -(at.value + 1)
+    # terms that read the coverage / mismatch tracks are refused; their no-op spellings are not
+    for spec, rc_want in ((b"R8-X5", _lib.E_UNSUPPORTED), (b"P3", _lib.E_UNSUPPORTED), (b"R8-N40-D8-X0", 0),
+                          (b"R8-N40-D8-P9999", 0)):
+        npol = _lib.lib().cramgpu_parse_policies(spec, arr, 32)
+        assert _lib.lib().cramgpu_tracks_windows(n, starts.ctypes.data, span.ctypes.data, rflags.ctypes.data,
+                                                 mapq.ctypes.data, arr, npol, 5400, 900, got.ctypes.data, None) == rc_want
+
+
+def reads_with(starts, like):
+    class R:
+        pass
+    r = R()
+    r.n, r.aln_start, r.aln_span, r.rflags, r.mapq = like.n, starts, like.aln_span, like.rflags, like.mapq
+    return r
 
 
 def test_substitution_matrix_matches_oracle_and_kat(orc, katrec):

@@ -8,6 +8,8 @@ from kat_inputs import fuzz_inputs, kat_input
 
 pytestmark = pytest.mark.gpu
 
+DEV = "cuda:0"  # the host-build glue test (tests/test_glue_hostsim.py) swaps in "cpu"
+
 
 @pytest.fixture(scope="module")
 def xc():
@@ -50,11 +52,11 @@ def test_empty_short_and_errors(xc, orc):
     assert xc.rans(b"", 0) == b"" and xc.rans(b"", 1) == b"" and xc.unrans(b"") == b""
     for d in (b"a", b"ab", b"abc"):
         assert xc.rans(d, 1) == orc.rans(d, 0)
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError, match=r"Unknown rANS order: 2$"):  # RANS.ORDER.fromInt's message, X filled in
         xc.rans(b"abcd", 2)
     c = xc.rans(b"abracadabra", 0)
-    with pytest.raises(RuntimeError):
-        xc.unrans(c[:-1])  # "Incorrect input length."
+    with pytest.raises(RuntimeError, match=r"Incorrect input length\."):
+        xc.unrans(c[:-1])
     bad = bytearray(c)
     bad[0] = 7
     with pytest.raises(RuntimeError):
@@ -127,3 +129,71 @@ def test_async_jobs(engine, orc):
     for (d, _), j in zip(batches, djobs):
         assert j.wait() == d
     assert engine.compress_many(*batches[1]) == outs[1]  # the synchronous path still works afterwards
+
+
+def test_two_streams_one_engine(engine, orc):
+    """Consecutive *_dev calls on DIFFERENT streams of one context share its scratch (descriptors, LPT permutation,
+    per-workgroup tables): the library orders them on the device with an event, so both batches come out right even
+    though nothing synchronises the two streams."""
+    import torch
+    from cramtools_amd import external_compression as xc
+    rng = np.random.default_rng(17)
+    batches = []
+    for k in range(2):
+        # wide alphabets use the per-workgroup global scratch, the thing two overlapping launches would trample
+        datas = [rng.integers(0, 256, 300000 + 1000 * k, dtype=np.uint8).tobytes() for _ in range(6)]
+        datas += [rng.integers(0, 7 + k, 50000, dtype=np.uint8).tobytes() for _ in range(6)]
+        batches.append(datas)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    res = []
+    for k in range(2):
+        datas = batches[k]
+        n = len(datas)
+        blocks, in_bytes, out_bytes = xc.Engine.plan_encode([len(d) for d in datas], [1] * n)
+        h_in = np.zeros(in_bytes, np.uint8)
+        for i, d in enumerate(datas):
+            h_in[blocks[i].in_off:blocks[i].in_off + len(d)] = np.frombuffer(d, np.uint8)
+        d_in = torch.as_tensor(h_in).to(DEV)
+        d_out = torch.zeros(out_bytes, dtype=torch.uint8, device=DEV)
+        d_len = torch.zeros(n, dtype=torch.int32, device=DEV)
+        d_pos = torch.zeros(n, dtype=torch.int64, device=DEV)
+        res.append((blocks, d_in, d_out, d_len, d_pos))
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in range(2):
+            blocks, d_in, d_out, d_len, d_pos = res[k]
+            engine.encode_dev(d_in, d_out, blocks, len(batches[k]), d_len, d_pos, stream=streams[k].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(2):
+        blocks, d_in, d_out, d_len, d_pos = res[k]
+        lens, pos, out = d_len.cpu().numpy(), d_pos.cpu().numpy(), d_out.cpu().numpy()
+        for i, d in enumerate(batches[k]):
+            assert out[pos[i]:pos[i] + lens[i]].tobytes() == orc.rans(d, 1), (k, i)
+
+
+def test_gather_reports_overflow(engine, orc):
+    """cramgpu_gather_dev with a destination one byte too small copies nothing and says so in d_dst_off[n]."""
+    import torch
+    from cramtools_amd import external_compression as xc
+    datas = [bytes([65 + (i * 7 + k) % 5 for i in range(3000 + 17 * k)]) for k in range(5)]
+    blocks, in_bytes, out_bytes = xc.Engine.plan_encode([len(d) for d in datas], [0] * 5)
+    h_in = np.zeros(in_bytes, np.uint8)
+    for i, d in enumerate(datas):
+        h_in[blocks[i].in_off:blocks[i].in_off + len(d)] = np.frombuffer(d, np.uint8)
+    d_in = torch.as_tensor(h_in).to(DEV)
+    d_out = torch.zeros(out_bytes, dtype=torch.uint8, device=DEV)
+    d_len = torch.zeros(5, dtype=torch.int32, device=DEV)
+    d_pos = torch.zeros(5, dtype=torch.int64, device=DEV)
+    engine.encode_dev(d_in, d_out, blocks, 5, d_len, d_pos)
+    want = [orc.rans(d, 0) for d in datas]
+    need = sum((len(w) + 15) // 16 * 16 for w in want)  # every piece is rounded up, the last one too
+    d_off = torch.zeros(6, dtype=torch.int64, device=DEV)
+    small = torch.full((need - 1,), 0x55, dtype=torch.uint8, device=DEV)
+    engine.gather_dev(d_out, d_pos, d_len, 5, max(b.out_cap for b in blocks[:5]), small, d_off)
+    torch.cuda.synchronize()
+    assert int(d_off[5]) == need and bool((small == 0x55).all())
+    exact = torch.zeros(need, dtype=torch.uint8, device=DEV)
+    engine.gather_dev(d_out, d_pos, d_len, 5, max(b.out_cap for b in blocks[:5]), exact, d_off)
+    torch.cuda.synchronize()
+    for i, w in enumerate(want):
+        assert exact[int(d_off[i]):int(d_off[i]) + len(w)].cpu().numpy().tobytes() == w

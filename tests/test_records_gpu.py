@@ -182,7 +182,16 @@ def test_random_containers_vs_oracle(rk, orc, long_reads):
         for r in range(n):
             if wst[r] == 0:
                 assert np.array_equal(o[woff[r]:woff[r] + lens[r]], wout[woff[r]:woff[r] + lens[r]]), r
-    for spec in ("N40-D8", "R8-N40-D8", "*8", "m5", "I40", "R8", "U8-P3"):
+    # pile-up terms that depend on the (unbuilt) coverage / mismatch tracks are refused, not answered with zero tracks
+    for spec in ("U8-P3", "R40-X5"):
+        qsp = records.QualityScorePreservation(eng, spec)
+        with pytest.raises(records.CramGpuError) as ei:
+            qsp.tracks_windows(st, o_reads.aln_span, rflags, mapq, len(ref), 1000000)
+        assert ei.value.code == -10
+        with pytest.raises(records.CramGpuError) as ei:
+            qsp.add_quality_scores(reads, d_ref, np.ones(n, np.int32), 1000000)
+        assert ei.value.code == -10
+    for spec in ("N40-D8", "R8-N40-D8", "*8", "m5", "I40", "R8", "U8-P9999", "R40-X0"):
         qsp = records.QualityScorePreservation(eng, spec)
         pols = orc.parse_policies(spec)
         for window in (1000000, 700):
@@ -334,3 +343,40 @@ def test_restore_quals_many_reads(rk, orc):
     for r in range(n):
         if wst[r] == 0:
             assert np.array_equal(g[off[r]:off[r] + lens[r]], want[off[r]:off[r] + lens[r]]), r
+
+
+def test_malformed_feature_positions(rk):
+    """Decode-side features come from a file: a Q / B position outside the read, or an S / I sequence outside the
+    sequence arena, makes the reference throw (CramNormalizer.java:302,307: scores[pos - 1]); the kernels report
+    CRAMGPU_E_JAVA_THROWS for that read and write nothing outside it."""
+    records, eng = rk
+    import torch
+    norm = records.CramNormalizer(eng)
+    for L in (20, 1500):  # the lane-per-read and the wave-per-read kernels
+        lens = np.array([L, L, L, L], np.int32)
+        rflags = np.zeros(4, np.uint8)  # not force-preserved: default score + Q / B patches
+        f_off = np.array([0, 1, 2, 3, 4], np.int64)
+        feats = dict(op=np.array([ord("Q"), ord("Q"), ord("B"), ord("Q")], np.uint8),
+                     pos=np.array([0, L + 1, L + 7, L], np.int32), a=np.array([9, 9, 65, 9], np.int32),
+                     b=np.array([0, 0, 9, 0], np.int32), off=f_off)
+        fb = records.FeatureBatch.from_host(DEV, feats["op"], feats["pos"], feats["a"], feats["b"], feats["off"])
+        guard = np.full(4 * L + 64, 0x55, np.uint8)
+        got, st = norm.restore_quality_scores(DEV, lens, rflags, fb, guard)
+        assert st.cpu().numpy().tolist() == [-9, -9, -9, 0]
+        g = got.cpu().numpy()
+        assert (g[4 * L:] == 0x55).all()  # nothing written behind the last read
+        assert g[4 * L - 1] == 9 and (g[3 * L:4 * L - 1] == 30).all()
+        # restoreReadBases: S feature whose bytes lie outside the sequence arena, I feature with a negative offset
+        ref = np.frombuffer(b"ACGT" * 1000, np.uint8)
+        d_ref = _dref(ref.tobytes())
+        feats = dict(op=np.array([ord("S"), ord("I"), ord("S")], np.uint8), pos=np.array([1, 2, 1], np.int32),
+                     a=np.array([10 ** 6, -5, 0], np.int32), b=np.array([4, 3, 4], np.int32),
+                     off=np.array([0, 1, 2, 3, 3], np.int64))
+        fb = records.FeatureBatch.from_host(DEV, feats["op"], feats["pos"], feats["a"], feats["b"], feats["off"])
+        seq = np.frombuffer(b"TTTTGGGGCCCCAAAA", np.uint8)
+        out, off, st = norm.restore_read_bases(DEV, lens, np.array([1, 1, 1, 1], np.int32), rflags, fb, d_ref,
+                                               [(0, ref.size, 0)], np.frombuffer(bytes.fromhex("1b1b1b1b1b"), np.uint8),
+                                               seq=seq, seq_off=np.zeros(4, np.int64))
+        assert st.cpu().numpy().tolist() == [-9, -9, 0, 0]
+        o = out.cpu().numpy()
+        assert o[2 * L:2 * L + 8].tobytes() == b"TTTTACGT"

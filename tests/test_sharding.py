@@ -38,6 +38,45 @@ def test_container_queue_orders_results():
     assert all(res == ("g%d" % (o % 3), (o + 100) * 2) for o, res in out)
 
 
+class _SlowEng:
+    def __init__(self, tag, seed):
+        import random
+        self.tag, self.rng = tag, random.Random(seed)
+
+    def run(self, job):
+        import time
+        time.sleep(self.rng.random() * 0.004)
+        return (self.tag, job * 2)
+
+
+def test_container_queue_orders_results_under_skew():
+    """Workers that finish at random times still hand their results on in ordinal order (the release list
+    used to be appended outside the ordering lock)."""
+    for seed in range(5):
+        q = sharding.ContainerQueue([_SlowEng("g%d" % g, 10 * seed + g) for g in range(4)])
+        for k in range(60):
+            q.submit(k, k)
+        out = q.run()
+        assert [o for o, _ in out] == list(range(60))
+
+
+def test_engine_coder_adapter():
+    class FakeEngine:
+        def compress_many(self, datas, orders):
+            return [bytes([o]) + d for d, o in zip(datas, orders)]
+
+        def uncompress_many(self, streams):
+            return [s[1:] for s in streams]
+    q = sharding.ContainerQueue([sharding.EngineCoder(FakeEngine()) for _ in range(2)])
+    for k in range(5):
+        q.submit(k, ([b"abc%d" % k], [k & 1]))
+    out = q.run()
+    assert [r for _, r in out] == [[bytes([k & 1]) + b"abc%d" % k] for k in range(5)]
+    q = sharding.ContainerQueue([sharding.EngineCoder(FakeEngine())])
+    q.submit(0, (out[0][1], None))
+    assert q.run() == [(0, [b"abc0"])]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
