@@ -20,9 +20,15 @@
 //                         states the chain logged for the previous batch into output bytes, placed with a
 //                         ballot/popcount prefix in the reference's emission order (state 3,2,1,0 per step) and
 //                         written from the end of the slot downwards, which realises Utils#reverse for free.
-//   wave 0 ("chain")   per step and state (lanes 0-3): one 16-byte LDS read, compare, conditional shift, mul_hi, shift,
-//                      24-bit multiply, add — Encoding#RansEncPutSymbol with everything state-independent removed —
-//                      and logs the pre-renormalisation states of a batch with four 16-byte LDS writes.
+//   wave 0 ("chain")   the "rotating" chain: state j lives in DPP row j (lanes 16j..16j+15) and step u of a half batch
+//                      runs in lane 16j + (u & 15) on THAT lane's own 16-byte record (one LDS read per lane per 16
+//                      steps instead of one per step); the state moves to the next lane with a row_ror:1 DPP move whose
+//                      bank mask leaves "state before my step" in one of four log registers, so that the log of a half
+//                      batch leaves as ONE 4-byte LDS write per lane.  Every lane executes every step (15 of 16 compute
+//                      garbage that is never read): a lone wave issues one vector instruction per ~4.4 cycles whatever
+//                      its EXEC mask, so idle lanes cost nothing and the per-step LDS traffic of a lane-resident state
+//                      is what goes away.  Per step: the DPP move, compare, conditional byte shift, mul_hi, shift,
+//                      24-bit multiply, add — Encoding#RansEncPutSymbol with everything state-independent removed.
 // The two waves meet at one workgroup barrier per batch; staging and log are double buffered.
 // Order-1 tables live in LDS over the compacted alphabet (present symbols + 0) when n*(n|1)*12 B fits the table
 // region, else (same dense layout) in a per-workgroup global scratch.
@@ -33,45 +39,60 @@
 namespace {
 
 constexpr int kSteps = 16;   // steps per half batch: 16 steps x 4 states = the 64 lanes of the helper wave
-constexpr int kHalves = 2;   // half batches between two barriers (amortises the barrier and the helper's fixed costs)
+constexpr int kHalves = 4;   // 16-step groups between two barriers (amortises the barrier and both waves' fixed costs)
 constexpr int kBatch = kSteps * kHalves;
+
+// records of a state are kStageRow apart: with 17 the helper's 16-byte stores (lanes = step-major) spread over the
+// banks (2-way instead of 4-way conflicts) and the chain wave's row-major reads stay conflict-free
+constexpr int kStageRow = 17;
 
 constexpr int kRingBytes = 4096;  // input ring of the helper wave: 4 x 1 KiB (order 1) or 1 x 4 KiB (order 0)
 
 // LDS of one workgroup, statically sized so that 4 workgroups fill the 160 KiB of a CU.
+struct EncP2 {              // phase 2 (tables)
+    uint32_t rowT[256];     // order-1 row totals (0 = context absent)
+    uint32_t rowoff[256];   // serialised length of each row
+    uint32_t rowhdr[256];   // context-level header of each row: count | byte0 << 8 | byte1 << 16
+};
+struct alignas(16) EncP3 {  // phase 3 (coding loop)
+    uint4 stage[3][kHalves][kStageRow * 4];  // [buffer][half][state*kStageRow + step]: x_max-1, rcp_freq, bias, cmpl_freq | shift<<24 | small<<31
+    uint32_t xs[2][kHalves][64];  // [buffer][half][state*16 + step]: state before each step of the batch
+    uint8_t ring[kRingBytes];  // input bytes (dense symbol indices when the order-1 tables are in LDS)
+    uint32_t gflag[3][kHalves];  // [buffer][half] != 0: the half batch holds a symbol with freq < 16
+    uint32_t fin[4];        // states after the last batch the chain ran
+    unsigned long long cbusy, cbusy2, cgen;  // profiling runs only: cycles the chain wave spent outside barriers
+};
 struct alignas(16) EncFixed {
-    union {
-        struct {                    // phase 2 (tables)
-            uint32_t rowT[256];     // order-1 row totals (0 = context absent)
-            uint32_t rowoff[256];   // serialised length of each row
-            uint32_t rowhdr[256];   // context-level header of each row: count | byte0 << 8 | byte1 << 16
-        } p2;
-        struct {                    // phase 3 (coding loop)
-            uint4 stage[2][kHalves][64];  // [buffer][half][step*4 + state]: x_max-1, rcp_freq, bias, cmpl_freq | shift<<24 | small<<31
-            uint4 xs[2][kHalves][4][4];   // [buffer][half][state][step/4]: state before each step of the batch
-            uint8_t ring[kRingBytes];  // input bytes (dense symbol indices when the order-1 tables are in LDS)
-            uint32_t gflag[2][kHalves];  // [buffer][half] != 0: the half batch holds a symbol with freq < 16
-            uint32_t fin[4];        // states after the last batch the chain ran
-            unsigned long long cbusy, cbusy2, cgen;  // profiling runs only: cycles the chain wave spent outside barriers
-        } p3;
-    };
     uint8_t dmap[256];    // byte value -> dense index
     uint8_t syml[256];    // dense index -> byte value
     // block hand-over between the waves (written by the helper wave, read by both after a barrier)
     int32_t mode, stride, ent_off, tab_len, status;
     uint32_t ticket;
     uint32_t pad[2];
+    // The union comes last, directly in front of the table region: the part of the coding loop's buffers that phase 2
+    // does not use (everything behind p2) is free during phases 1 and 2 and forms, together with the table region, one
+    // contiguous "big" area for what only those phases need (pair counters, histogram words, staged rows).
+    union {
+        EncP2 p2;
+        EncP3 p3;
+    };
 };
-constexpr int kTabBytes = ((160 * 1024 / 4 - (int)sizeof(EncFixed)) & ~255) - 256;  // table region (counts, symbols, replicas)
+static_assert(sizeof(EncP3) % 16 == 0 && sizeof(EncP2) % 16 == 0, "the spare area starts and ends on 16-byte boundaries");
+constexpr int kTabBytes = ((160 * 1024 / 4 - (int)sizeof(EncFixed)) & ~255) - 256;  // table region (symbols, counts, replicas)
+constexpr int kSpareBytes = (int)sizeof(EncP3) - (int)sizeof(EncP2);               // free in phases 1 and 2
+constexpr int kBigBytes = kSpareBytes + kTabBytes;
 struct alignas(16) EncLds : EncFixed {
     alignas(16) uint8_t tab[kTabBytes];
 };
+static_assert(sizeof(EncLds) == sizeof(EncFixed) + kTabBytes, "table region directly behind the coding-loop buffers");
 typedef EncLds EncFixedLds;  // phases 1 and 2 only touch the fixed part
 #ifdef HIP_SIM
 static EncLds lds;
 #else
 __shared__ EncLds lds;
 #endif
+// start of the big area (kBigBytes): behind p2, through the rest of p3 and the whole table region
+__device__ __forceinline__ uint8_t* lds_big() { return reinterpret_cast<uint8_t*>(&lds.p3) + sizeof(EncP2); }
 
 // A value that is the same in every lane of the wave, moved to a scalar register so that branches on it are scalar
 // branches: a wave then never walks a path of the other wave's role with an empty EXEC mask (where a barrier would
@@ -777,11 +798,13 @@ __device__ __forceinline__ uint2 lookup_entry(const Cursor& c, const uint8_t* ri
     return ent[act ? idx : 0u];  // an inactive pair may hold a stale ring byte: no stray table reads
 }
 
-// Encoding#RansEncPutSymbol L46-71 for 16 steps of one state (chain wave, lanes 0-3 = states 0-3); the state before
-// every step is logged to xs[step] for the helper wave.  The renormalisation test is arithmetic — the sign of
+// Encoding#RansEncPutSymbol L46-71 for the 16 steps of a half batch, all four states (chain wave, rotating layout:
+// lane 16j + t holds the record of step t of state j).  The renormalisation test is arithmetic — the sign of
 // (x_max - 1) - x selects a byte shift (v_alignbyte) — because a compare + select through VCC needs two idle issue
 // slots between them on gfx950 (scripts/ubench/seq_bench.hip: 14.0 vs 18.3 cycles).
-// GENERAL: the batch holds symbols with freq < 16, whose first renormalisation byte is certain (x >= L > x_max).
+// GENERAL: the half batch holds symbols with freq < 16, whose first renormalisation byte is certain (x >= L > x_max):
+// sm = 1 in the lanes of such records.
+// Returns the state after the half batch (valid in lane 15 of every row); lg = the state before this lane's step.
 __device__ __forceinline__ uint32_t shr_bytes(uint32_t x, uint32_t nbytes) {
 #ifdef HIP_SIM
     return x >> (8u * (nbytes & 3u));
@@ -789,64 +812,72 @@ __device__ __forceinline__ uint32_t shr_bytes(uint32_t x, uint32_t nbytes) {
     return __builtin_amdgcn_alignbyte(0u, x, nbytes);
 #endif
 }
+#ifdef HIP_SIM
+struct LogRegs {
+    uint32_t l0, l1, l2, l3;
+};
 template <bool GENERAL>
-__device__ __forceinline__ uint32_t chain_steps(uint32_t x, const uint4 (&P)[kSteps], uint4* xs) {
-    uint32_t xl[kSteps];
-#pragma unroll
+__device__ __forceinline__ uint32_t rot_steps(uint32_t x, const uint4 P, uint32_t sm, LogRegs&, uint32_t& lg) {
+    const int l = lane_id();
     for (int tt = 0; tt < kSteps; tt++) {
-        xl[tt] = x;
-        if (GENERAL) x = shr_bytes(x, P[tt].w >> 31);
-        const uint32_t xr = shr_bytes(x, (P[tt].x - x) >> 31);
-        const uint32_t qq = __umulhi(xr, P[tt].y) >> ((P[tt].w >> 24) & 31u);  // qq < 2^19, cmpl_freq < 2^12
-        x = xr + P[tt].z + __umul24(qq, P[tt].w);
+        const uint32_t xin = __shfl(x, (l & 48) | ((l - 1) & 15));  // row_ror:1
+        if (tt == (l & 15)) lg = xin;
+        uint32_t p = xin;
+        if (GENERAL) p = shr_bytes(p, sm);
+        const uint32_t xr = shr_bytes(p, (P.x - p) >> 31);
+        const uint32_t qq = __umulhi(xr, P.y) >> ((P.w >> 24) & 31u);  // qq < 2^19, cmpl_freq < 2^12
+        x = xr + P.z + __umul24(qq, P.w);
     }
-#pragma unroll
-    for (int k = 0; k < kSteps / 4; k++) xs[k] = make_uint4(xl[4 * k], xl[4 * k + 1], xl[4 * k + 2], xl[4 * k + 3]);
     return x;
 }
-
-#ifndef HIP_SIM
-// The same steps as straight-line assembly, 7 instructions per step (9 in a general half batch), every state in its own
-// register so that the log leaves as one 16-byte LDS write per four steps (an LDS instruction costs the issuing
-// wave 8-20 cycles, three to four times a vector instruction).  The shift count is byte 3 of the record's last word
-// (SDWA), the 24-bit multiply ignores that byte.
-#define RANS_CORE(XI, XO, K)                                                                                  \
-    "v_sub_u32 %[t], %[a" #K "], %[" #XI "]\n\t"                                                              \
-    "v_lshrrev_b32 %[t], 31, %[t]\n\t"                                                                        \
-    "v_alignbyte_b32 %[r], 0, %[" #XI "], %[t]\n\t"                                                           \
-    "v_mul_hi_u32 %[m], %[r], %[b" #K "]\n\t"                                                                 \
-    "v_lshrrev_b32_sdwa %[m], %[d" #K "], %[m] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t" \
-    "v_mul_u32_u24 %[m], %[m], %[d" #K "]\n\t"                                                                \
-    "v_add3_u32 %[" #XO "], %[r], %[c" #K "], %[m]\n\t"
-#define RANS_STEP(XI, XO, K) RANS_CORE(XI, XO, K)
-// general step: a record with bit 31 set (freq < 16) first drops the byte that is certain to leave
-#define RANS_STEP_G(XI, XO, K)                                                                                \
-    "v_lshrrev_b32 %[t], 31, %[d" #K "]\n\t"                                                                  \
-    "v_alignbyte_b32 %[p], 0, %[" #XI "], %[t]\n\t" RANS_CORE(p, XO, K)
-#define RANS_OPERANDS                                                                                          \
-    [x0] "v"(x0), [a0] "v"(P[g].x), [b0] "v"(P[g].y), [c0] "v"(P[g].z), [d0] "v"(P[g].w), [a1] "v"(P[g + 1].x),     \
-        [b1] "v"(P[g + 1].y), [c1] "v"(P[g + 1].z), [d1] "v"(P[g + 1].w), [a2] "v"(P[g + 2].x), [b2] "v"(P[g + 2].y), \
-        [c2] "v"(P[g + 2].z), [d2] "v"(P[g + 2].w), [a3] "v"(P[g + 3].x), [b3] "v"(P[g + 3].y), [c3] "v"(P[g + 3].z), \
-        [d3] "v"(P[g + 3].w)
+#else
+// Straight-line assembly, 8 vector instructions per step (9 in a general half batch).  A DPP operand read straight
+// behind the VALU write of the same register returns the OLD value on gfx950 (scripts/ubench/rot_bench.hip: wrong
+// states without a gap, right ones with one instruction in between), hence the s_nop in front of every move.  The
+// move of step t writes only the bank (4 lanes) of lane t, into log register t & 3: a lane's own "state before my
+// step" is written exactly once per half batch, to register (lane & 3).  The shift count of the quotient is byte 3
+// of the record's last word (SDWA), the 24-bit multiply ignores that byte.  Three selects under constant lane masks
+// then gather the four log registers into one (register k is the right one in the lanes with lane & 3 == k).
+struct LogRegs {  // live across half batches only so that they need no initialisation per half
+    uint32_t l0, l1, l2, l3;
+};
+#define ROT_CORE(SRC)                                                                                              \
+    "v_sub_u32 %[t], %[a], %[" #SRC "]\n\t"                                                                        \
+    "v_lshrrev_b32 %[t], 31, %[t]\n\t"                                                                             \
+    "v_alignbyte_b32 %[r], 0, %[" #SRC "], %[t]\n\t"                                                               \
+    "v_mul_hi_u32 %[m], %[r], %[b]\n\t"                                                                            \
+    "v_lshrrev_b32_sdwa %[m], %[d], %[m] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"   \
+    "v_mul_u32_u24 %[m], %[m], %[d]\n\t"                                                                           \
+    "v_add3_u32 %[x], %[r], %[c], %[m]\n\t"
+#define ROT_STEP(LG, BK)                                                                                           \
+    "s_nop 0\n\t"                                                                                                  \
+    "v_mov_b32_dpp %[" #LG "], %[x] row_ror:1 row_mask:0xf bank_mask:" #BK "\n\t" ROT_CORE(LG)
+#define ROT_STEP_G(LG, BK)                                                                                         \
+    "s_nop 0\n\t"                                                                                                  \
+    "v_mov_b32_dpp %[" #LG "], %[x] row_ror:1 row_mask:0xf bank_mask:" #BK "\n\t"                                  \
+    "v_alignbyte_b32 %[p], 0, %[" #LG "], %[sm]\n\t" ROT_CORE(p)
+#define ROT4(STEP, BK) STEP(l0, BK) STEP(l1, BK) STEP(l2, BK) STEP(l3, BK)
+#define ROT16(STEP) ROT4(STEP, 0x1) ROT4(STEP, 0x2) ROT4(STEP, 0x4) ROT4(STEP, 0x8)
+#define ROT_SELECT                                                \
+    "v_cndmask_b32_e64 %[lg], %[l0], %[l1], %[k1]\n\t"            \
+    "v_cndmask_b32_e64 %[lg], %[lg], %[l2], %[k2]\n\t"            \
+    "v_cndmask_b32_e64 %[lg], %[lg], %[l3], %[k3]\n\t"
 template <bool GENERAL>
-__device__ __forceinline__ uint32_t chain_steps_asm(uint32_t x0, const uint4 (&P)[kSteps], uint4* xs) {
-#pragma unroll
-    for (int g = 0; g < kSteps; g += 4) {
-        uint32_t x1, x2, x3, x4, t, r, m, p;
-        if (GENERAL)
-            asm volatile(RANS_STEP_G(x0, x1, 0) RANS_STEP_G(x1, x2, 1) RANS_STEP_G(x2, x3, 2) RANS_STEP_G(x3, x4, 3)
-                         : [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [t] "=&v"(t), [r] "=&v"(r),
-                           [m] "=&v"(m), [p] "=&v"(p)
-                         : RANS_OPERANDS);
-        else
-            asm volatile(RANS_STEP(x0, x1, 0) RANS_STEP(x1, x2, 1) RANS_STEP(x2, x3, 2) RANS_STEP(x3, x4, 3)
-                         : [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [t] "=&v"(t), [r] "=&v"(r),
-                           [m] "=&v"(m)
-                         : RANS_OPERANDS);
-        xs[g >> 2] = make_uint4(x0, x1, x2, x3);
-        x0 = x4;
-    }
-    return x0;
+__device__ __forceinline__ uint32_t rot_steps(uint32_t x, const uint4 P, uint32_t sm, LogRegs& G, uint32_t& lg) {
+    uint32_t t, r, m, p;
+    const unsigned long long k1 = 0x2222222222222222ull, k2 = 0x4444444444444444ull, k3 = 0x8888888888888888ull;
+    if (GENERAL)
+        asm volatile(ROT16(ROT_STEP_G) ROT_SELECT
+                     : [x] "+v"(x), [l0] "+v"(G.l0), [l1] "+v"(G.l1), [l2] "+v"(G.l2), [l3] "+v"(G.l3), [t] "=&v"(t),
+                       [r] "=&v"(r), [m] "=&v"(m), [p] "=&v"(p), [lg] "=&v"(lg)
+                     : [a] "v"(P.x), [b] "v"(P.y), [c] "v"(P.z), [d] "v"(P.w), [sm] "v"(sm), [k1] "s"(k1), [k2] "s"(k2),
+                       [k3] "s"(k3));
+    else
+        asm volatile(ROT16(ROT_STEP) ROT_SELECT
+                     : [x] "+v"(x), [l0] "+v"(G.l0), [l1] "+v"(G.l1), [l2] "+v"(G.l2), [l3] "+v"(G.l3), [t] "=&v"(t),
+                       [r] "=&v"(r), [m] "=&v"(m), [lg] "=&v"(lg)
+                     : [a] "v"(P.x), [b] "v"(P.y), [c] "v"(P.z), [d] "v"(P.w), [k1] "s"(k1), [k2] "s"(k2), [k3] "s"(k3));
+    return x;
 }
 #endif
 
@@ -871,8 +902,9 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
     const int32_t n = UNIFORM(n_), stride = UNIFORM(stride_), room = UNIFORM(room_);  // arrive in vector registers
     const int l = lane_id();
     const bool helper = wave_id() == 1;
-    const int t = l >> 2, j = 3 - (l & 3);
-    const int slot = t * 4 + j;
+    const int t = l >> 2, j = 3 - (l & 3);   // helper lane -> (step, state): lane order = emission order
+    const int slot = j * kStageRow + t;      // its record in the staging area
+    const int cslot = (l >> 4) * kStageRow + (l & 15);  // chain lane 16j + t -> the same record
     Geo g;
     g.n = n;
     g.q = n >> 2;
@@ -881,15 +913,19 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
     const int32_t nbatch = (g.U + kBatch - 1) / kBatch;
     const int32_t limit = room - 16;
     const uint4 ident = make_uint4(0x7FFFFFFFu, 0u, 0u, 0u);  // identity step for inactive (step, state) pairs (x < 2^31)
-    uint32_t x = RANS_BYTE_L;  // chain wave
-    // helper wave, per half batch: records of batch i and batch i-1, looked-up symbol of batch i+2 (then i+1)
-    uint4 A0[kHalves], A1[kHalves];
+    uint32_t x = RANS_BYTE_L;  // chain wave: the state of row j, on its way round the row
+    LogRegs logs{0u, 0u, 0u, 0u};
+    // helper wave, per half batch: x_max - 1 and the word with the freq < 16 flag of the records of batches i+1, i, i-1
+    // at the start of iteration i (Ax/Aw[0], [1], [2]: what the byte emission of a batch needs of its records, kept
+    // until the chain has logged that batch), looked-up symbol of batch i+3
+    uint32_t Ax[3][kHalves], Aw[3][kHalves];
     uint2 e2[kHalves];
     bool act2[kHalves];
     Cursor cur[kHalves];
 #pragma unroll
     for (int h = 0; h < kHalves; h++) {
-        A0[h] = A1[h] = ident;
+#pragma unroll
+        for (int q = 0; q < 3; q++) Ax[q][h] = ident.x, Aw[q][h] = 0u;
         e2[h] = make_uint2(0u, 0u);
         act2[h] = false;
         cur[h] = cursor_init<MODE>(g, h * kSteps + t, j);
@@ -897,20 +933,27 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
     ChunkRegs CR;
     int32_t run = 0;
     bool failed = false;
+    // Staging is three batches deep: in iteration i the chain wave runs batch i from registers and fetches the records
+    // of batch i+1 (staged in iteration i-1, visible since the barrier that ended it) while the helper stages batch
+    // i+2 — no iteration of the chain begins by waiting for an LDS round trip.
     if (helper) {
         chunk_load<MODE>(src, g, 0, l, CR);
         chunk_store<MODE>(CR, L->p3.ring, L->dmap);
         chunk_load<MODE>(src, g, 1, l, CR);
         WSYNC();
 #pragma unroll
-        for (int h = 0; h < kHalves; h++) {
-            bool act0;
-            const uint2 e0 = lookup_entry<MODE>(cur[h], L->p3.ring, ent, stride, act0);
-            cursor_next<MODE>(cur[h]);
-            A0[h] = act0 ? expand_symbol(e0) : ident;
-            const unsigned long long sm = __ballot((int32_t)A0[h].w < 0);
-            L->p3.stage[0][h][slot] = A0[h];
-            if (l == 0) L->p3.gflag[0][h] = sm != 0 ? 1u : 0u;  // this half needs the general chain
+        for (int b0 = 0; b0 < 2; b0++) {  // batches 0 and 1
+#pragma unroll
+            for (int h = 0; h < kHalves; h++) {
+                bool act0;
+                const uint2 e0 = lookup_entry<MODE>(cur[h], L->p3.ring, ent, stride, act0);
+                cursor_next<MODE>(cur[h]);
+                const uint4 A = act0 ? expand_symbol(e0) : ident;
+                const unsigned long long sm = __ballot((int32_t)A.w < 0);
+                L->p3.stage[b0][h][slot] = A;
+                if (l == 0) L->p3.gflag[b0][h] = sm != 0 ? 1u : 0u;  // this half needs the general chain
+                Ax[1 - b0][h] = A.x, Aw[1 - b0][h] = A.w;  // batch 0 -> slot 1, batch 1 -> slot 0
+            }
         }
 #pragma unroll
         for (int h = 0; h < kHalves; h++) {
@@ -922,54 +965,70 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
 #ifndef HIP_SIM
     if (!helper) __builtin_amdgcn_s_setprio(3);  // the chain wave is the critical path of the block
 #endif
+    // chain wave: records and flags of the batch about to run
+    uint4 Pc[kHalves];
+    uint32_t fc[kHalves];
+    if (!helper) {
+#pragma unroll
+        for (int h = 0; h < kHalves; h++) {
+            fc[h] = L->p3.gflag[0][h];
+            Pc[h] = L->p3.stage[0][h][cslot];
+        }
+    }
     unsigned long long busy = 0, busy2 = 0, ngen = 0;
+    int sb = 0;  // staging buffer of batch i (i mod 3)
     for (int32_t i = 0; i <= nbatch; i++) {
         const int buf = i & 1;
+        const int sb1 = sb == 2 ? 0 : sb + 1, sb2 = sb1 == 2 ? 0 : sb1 + 1;
         const long long tb = prof ? clock64() : 0;
         if (!helper) {
-            if (i < nbatch && l < 4) {
+            if (i < nbatch) {
+                // batch i+1's records and flags: the reads land while batch i runs
+                uint4 Pn[kHalves];
+                uint32_t fn[kHalves];
 #pragma unroll
                 for (int h = 0; h < kHalves; h++) {
-                    // the flag is read first and from its own word: waiting for it does not wait for the sixteen records
-                    const uint32_t fw = L->p3.gflag[buf][h];
-                    uint4 P[kSteps];
+                    fn[h] = L->p3.gflag[sb1][h];
+                    Pn[h] = L->p3.stage[sb1][h][cslot];
+                }
 #pragma unroll
-                    for (int tt = 0; tt < kSteps; tt++) P[tt] = L->p3.stage[buf][h][tt * 4 + l];
-                    uint4* xs = &L->p3.xs[buf][h][l][0];
-                    const bool general = UNIFORM(fw) != 0;
+                for (int h = 0; h < kHalves; h++) {
+                    const bool general = UNIFORM(fc[h]) != 0;
                     if (prof && h == 0) busy2 += (unsigned long long)(clock64() - tb);
                     if (prof && general) ngen++;
-#ifdef HIP_SIM
-                    x = general ? chain_steps<true>(x, P, xs) : chain_steps<false>(x, P, xs);
-#else
-                    x = general ? chain_steps_asm<true>(x, P, xs) : chain_steps_asm<false>(x, P, xs);
-#endif
+                    uint32_t lg;
+                    x = general ? rot_steps<true>(x, Pc[h], Pc[h].w >> 31, logs, lg) : rot_steps<false>(x, Pc[h], 0u, logs, lg);
+                    L->p3.xs[buf][h][l] = lg;
                 }
-                L->p3.fin[l] = x;
+                if ((l & 15) == 15) L->p3.fin[l >> 4] = x;
+#pragma unroll
+                for (int h = 0; h < kHalves; h++) Pc[h] = Pn[h], fc[h] = fn[h];
             }
         } else {
             // the log of batch i-1 (garbage in iteration 0, masked below)
             uint32_t xv[kHalves];
 #pragma unroll
             for (int h = 0; h < kHalves; h++)
-                xv[h] = reinterpret_cast<const uint32_t*>(&L->p3.xs[buf ^ 1][h][0][0])[j * kSteps + t];
-            // batch i+1: expand the symbols looked up one iteration ago
-            uint4 An[kHalves];
+                xv[h] = L->p3.xs[buf ^ 1][h][j * kSteps + t];
+            // batch i+2: expand the symbols looked up one iteration ago
+            uint32_t Anx[kHalves], Anw[kHalves];
 #pragma unroll
             for (int h = 0; h < kHalves; h++) {
-                An[h] = act2[h] ? expand_symbol(e2[h]) : ident;
-                const unsigned long long sm = __ballot((int32_t)An[h].w < 0);
-                L->p3.stage[buf ^ 1][h][slot] = An[h];
-                if (l == 0) L->p3.gflag[buf ^ 1][h] = sm != 0 ? 1u : 0u;
+                const uint4 An = act2[h] ? expand_symbol(e2[h]) : ident;
+                const unsigned long long sm = __ballot((int32_t)An.w < 0);
+                L->p3.stage[sb2][h][slot] = An;
+                if (l == 0) L->p3.gflag[sb2][h] = sm != 0 ? 1u : 0u;
+                Anx[h] = An.x, Anw[h] = An.w;
             }
-            // input ring: chunk c is needed from iteration 8c - 2 on; it is written at 8c - 4 from the registers that
-            // were loaded at 8c - 12, and the next chunk's loads are issued
-            if ((i & (kChunkBatches - 1)) == kChunkBatches / 2) {
+            // input ring: chunk c (kChunkBatches batches) is needed from iteration c * kChunkBatches - 3 on (the lookup
+            // of batch i + 3 below); it is written at (c - 1) * kChunkBatches from the registers that were loaded one
+            // chunk of iterations earlier, and the next chunk's loads are issued
+            if ((i & (kChunkBatches - 1)) == 0) {
                 chunk_store<MODE>(CR, L->p3.ring, L->dmap);
-                chunk_load<MODE>(src, g, (i + kChunkBatches / 2) / kChunkBatches + 1, l, CR);
+                chunk_load<MODE>(src, g, i / kChunkBatches + 2, l, CR);
                 WSYNC();
             }
-            // batch i+2: symbol lookup (the table reads land while this wave is at the barrier)
+            // batch i+3: symbol lookup (the table reads land while this wave is at the barrier)
 #pragma unroll
             for (int h = 0; h < kHalves; h++) {
                 e2[h] = lookup_entry<MODE>(cur[h], L->p3.ring, ent, stride, act2[h]);
@@ -978,9 +1037,9 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
             // bytes of batch i-1 in the reference's emission order (state 3,2,1,0 per step = lane order)
 #pragma unroll
             for (int h = 0; h < kHalves; h++) {
-                const bool small = (int32_t)A1[h].w < 0;
+                const bool small = (int32_t)Aw[2][h] < 0;
                 const uint32_t x1 = small ? xv[h] >> 8 : xv[h];
-                int nb = (small ? 1 : 0) + (x1 > A1[h].x ? 1 : 0);
+                int nb = (small ? 1 : 0) + (x1 > Ax[2][h] ? 1 : 0);
                 if (i == 0) nb = 0;
                 const unsigned long long m1 = __ballot(nb >= 1), m2 = __ballot(nb == 2);
                 const int32_t tot = __popcll(m1) + __popcll(m2);
@@ -991,12 +1050,14 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
                     if (nb == 2) pend[-2 - idx] = (uint8_t)(xv[h] >> 8);
                     run += tot;
                 }
-                A1[h] = A0[h];
-                A0[h] = An[h];
+                Ax[2][h] = Ax[1][h], Aw[2][h] = Aw[1][h];
+                Ax[1][h] = Ax[0][h], Aw[1][h] = Aw[0][h];
+                Ax[0][h] = Anx[h], Aw[0][h] = Anw[h];
             }
         }
         if (prof) busy += (unsigned long long)(clock64() - tb);
         pair_barrier();
+        sb = sb1;
     }
 #ifndef HIP_SIM
     if (!helper) __builtin_amdgcn_s_setprio(0);
@@ -1109,28 +1170,30 @@ __device__ __attribute__((noinline)) Prep prep_o1(Blk B) {
     const int ns = (int)nsym;
     const int stride = ns | 1;
     const int cells = ns * stride;
-    const bool in_lds = 12 * cells + 16 <= kTabBytes;
+    // in LDS: packed symbols (8 B per cell, needed by the coding loop) in the table region, pair counts (4 B per cell,
+    // dead once the symbols exist) in the spare area
+    const bool in_lds = 8 * cells + 16 <= kTabBytes && 4 * cells + 16 <= kSpareBytes;
     Prep r{in_lds ? MODE_O1_LDS : MODE_O1_GLOBAL, stride, 0, 0, 0};
     uint32_t* cnt;
     uint2* ent;
     uint32_t* rep = nullptr;
     int R = 1;
     const int rstride = cells | 1;
+    uint8_t* big = lds_big();
     if (in_lds) {
-        cnt = reinterpret_cast<uint32_t*>(tab);
-        const int ent_off = (4 * cells + 15) & ~15;
-        ent = reinterpret_cast<uint2*>(tab + ent_off);
-        const int rep_off = ent_off + 8 * cells;
+        cnt = reinterpret_cast<uint32_t*>(big);
+        ent = reinterpret_cast<uint2*>(tab);
+        const int rep_off = (8 * cells + 15) & ~15;
         while (R < 32 && rep_off + 2 * R * rstride * 4 <= kTabBytes) R <<= 1;
         rep = reinterpret_cast<uint32_t*>(tab + rep_off);
-        r.ent_off = ent_off;
+        r.ent_off = 0;
     } else {
         cnt = reinterpret_cast<uint32_t*>(B.gs);
         ent = reinterpret_cast<uint2*>(B.gs + kGsEntOff);
     }
-    const bool packed = !in_lds && B.n < 65536 && 2 * cells + 8 <= kTabBytes;
+    const bool packed = !in_lds && B.n < 65536 && 2 * cells + 8 <= kBigBytes;
     if (packed) {
-        hist_o1_packed16(B.src, B.n, cnt, stride, L->dmap, reinterpret_cast<uint32_t*>(tab), cells);
+        hist_o1_packed16(B.src, B.n, cnt, stride, L->dmap, reinterpret_cast<uint32_t*>(big), cells);
     } else {
         for (int i = l; i < cells; i += 64) cnt[i] = 0;
         if (!in_lds) __threadfence();  // the scratch was another block's a moment ago: write back / invalidate around each phase
@@ -1142,8 +1205,8 @@ __device__ __attribute__((noinline)) Prep prep_o1(Blk B) {
     if (in_lds) {
         r.tab_len = tables_o1(cnt, ent, ns, ns, stride, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
     } else {
-        const int G = min(64, kTabBytes / (stride * 4));  // >= 32 rows of the widest alphabet
-        r.tab_len = tables_o1_staged(cnt, ent, ns, stride, L, reinterpret_cast<uint32_t*>(tab), G, B.slot + 9, B.rcp_tab,
+        const int G = min(64, kBigBytes / (stride * 4));  // >= 32 rows of the widest alphabet
+        r.tab_len = tables_o1_staged(cnt, ent, ns, stride, L, reinterpret_cast<uint32_t*>(big), G, B.slot + 9, B.rcp_tab,
                                      B.cap - 9 - 16);
     }
     if (!in_lds) __threadfence();
