@@ -48,18 +48,65 @@ def gpu_insert_bases(eng, reads, ref, n_reads):
     return feats.op[:n].clone(), feats.a[:n].clone(), feats.off.clone()
 
 
-def build_workload(dev, n_reads, ref_len, read_len, seed_shift, features_of):
+def _concat_read_sets(parts, dev):
+    """Read sets of consecutive contigs as one (offsets shifted; the 16-byte / 1-element tails of each part dropped)."""
+    out = synth_torch.ReadSet()
+    out.n = sum(p.n for p in parts)
+    b_off = c_off = 0
+    base_off, cigar_off, bases, quals, cigar = [], [], [], [], []
+    for p in parts:
+        nb, ncg = p.bases.numel() - 16, p.cigar.numel() - 1
+        base_off.append(p.base_off + b_off)
+        cigar_off.append(p.cigar_off + c_off)
+        bases.append(p.bases[:nb])
+        quals.append(p.quals[:nb])
+        cigar.append(p.cigar[:ncg])
+        b_off += nb
+        c_off += ncg
+    pad = torch.zeros(16, dtype=torch.uint8, device=dev)
+    out.bases, out.quals = torch.cat(bases + [pad]), torch.cat(quals + [pad])
+    out.cigar = torch.cat(cigar + [torch.zeros(1, dtype=torch.int32, device=dev)])
+    out.base_off, out.cigar_off = torch.cat(base_off), torch.cat(cigar_off)
+    for name in ("read_len", "aln_start", "n_cigar", "mapq", "rflags", "aln_span", "flags_rnd"):
+        setattr(out, name, torch.cat([getattr(p, name) for p in parts]))
+    return out
+
+
+def build_workload(dev, n_reads, ref_len, read_len, seed_shift, features_of, n_contigs=1):
     """Reads + reference + the per-container external-block corpus, all on `dev`.
-    features_of(reads, ref) -> (op, a, off) of the reads' features (the GPU kernel in the bench, the oracle in tests)."""
-    ref = synth_torch.reference(ref_len, device=dev)
-    ref = torch.cat([ref, torch.zeros(16, dtype=torch.uint8, device=dev)])
-    rs = synth_torch.make_reads(n_reads, ref[:ref_len], read_len=read_len, seed=1 + seed_shift, qual_seed=2 + seed_shift,
-                                err_seed=3 + seed_shift)
-    n_cont = (n_reads + READS_PER_CONTAINER - 1) // READS_PER_CONTAINER
+    features_of(reads, ref) -> (op, a, off) of the reads' features (the GPU kernel in the bench, the oracle in tests).
+    n_contigs > 1 (the per-GPU shard shape of configs[3]): the reference is n_contigs contigs of ref_len / n_contigs
+    bases back to back in one arena (16-byte aligned starts), every contig gets the same share of the reads (a whole
+    number of containers: CRAMContainerStreamWriter flushes on a reference change), alignment starts are contig-local
+    and every container's window names its contig (non-zero ref_off)."""
+    if n_contigs == 1:
+        ref = synth_torch.reference(ref_len, device=dev)
+        ref = torch.cat([ref, torch.zeros(16, dtype=torch.uint8, device=dev)])
+        rs = synth_torch.make_reads(n_reads, ref[:ref_len], read_len=read_len, seed=1 + seed_shift, qual_seed=2 + seed_shift,
+                                    err_seed=3 + seed_shift)
+        n_cont = (n_reads + READS_PER_CONTAINER - 1) // READS_PER_CONTAINER
+        windows = [(0, ref_len, 0)] * n_cont
+    else:
+        per = n_reads // n_contigs
+        assert per * n_contigs == n_reads and per % READS_PER_CONTAINER == 0, "whole containers per contig"
+        clen = ref_len // n_contigs
+        stride = (clen + 15) // 16 * 16 + 16
+        whole = synth_torch.reference(clen * n_contigs, device=dev)
+        ref = torch.zeros(stride * n_contigs + 16, dtype=torch.uint8, device=dev)
+        parts, windows = [], []
+        for k in range(n_contigs):
+            ref[k * stride:k * stride + clen] = whole[k * clen:(k + 1) * clen]
+            parts.append(synth_torch.make_reads(per, ref[k * stride:k * stride + clen], read_len=read_len,
+                                                seed=1 + seed_shift + 7 * k, qual_seed=2 + seed_shift + 7 * k,
+                                                err_seed=3 + seed_shift + 7 * k))
+            windows += [(k * stride, clen, 0)] * (per // READS_PER_CONTAINER)
+        del whole
+        rs = _concat_read_sets(parts, dev)
+        del parts
+        n_cont = n_reads // READS_PER_CONTAINER
     read_cont = (torch.arange(n_reads, device=dev) // READS_PER_CONTAINER).to(torch.int32)
     reads = rec.ReadBatch(dev, rs.bases, rs.base_off, rs.read_len, rs.aln_start, rs.cigar, rs.cigar_off, rs.n_cigar,
-                          quals=rs.quals, mapq=rs.mapq, rflags=rs.rflags, read_cont=read_cont,
-                          windows=[(0, ref_len, 0)] * n_cont)
+                          quals=rs.quals, mapq=rs.mapq, rflags=rs.rflags, read_cont=read_cont, windows=windows)
     # ---- value series of the records (synthetic but shaped like the reference's) ----
     fr = rs.flags_rnd
     cont_first = torch.arange(n_cont, device=dev) * READS_PER_CONTAINER

@@ -46,6 +46,8 @@ constexpr int kBatch = kSteps * kHalves;
 // banks (2-way instead of 4-way conflicts) and the chain wave's row-major reads stay conflict-free
 constexpr int kStageRow = 17;
 
+constexpr int kWgThreads = 128;   // chain wave + helper wave
+
 constexpr int kRingBytes = 4096;  // input ring of the helper wave: 4 x 1 KiB (order 1) or 1 x 4 KiB (order 0)
 
 // LDS of one workgroup, statically sized so that 4 workgroups fill the 160 KiB of a CU.
@@ -180,13 +182,14 @@ __device__ __forceinline__ uint4 expand_symbol(uint2 e) {
 // ---------------------------------------------------------------------------------------------------------
 // phase 1: histograms
 // ---------------------------------------------------------------------------------------------------------
-// The histogram passes read the block in 16-byte units, unit k of a sweep at byte (sweep * 64 + lane) * 16.  A sweep is
+// Both waves of the workgroup count (the chain wave has nothing else to do until the tables exist): tid = 0..127.
+// The histogram passes read the block in 16-byte units, unit k of a sweep at byte (sweep * 128 + tid) * 16.  A sweep is
 // ~200-400 cycles of LDS atomics against ~1-2 us of load latency, so four sweeps are kept in flight in four fixed
 // registers (a rotating register would make the compiler wait at the copy).  F(v, i, prev): unit v at byte i, prev =
 // the byte before it (0 at i == 0; only loaded when WITH_PREV).
 template <bool WITH_PREV, class F>
 __device__ __forceinline__ void for_each_unit(const uint8_t* src, int32_t n16, int l, F f) {
-    constexpr int32_t kSweep = 64 * 16;
+    constexpr int32_t kSweep = kWgThreads * 16;
     uint4 v[4];
     uint32_t pv[4];
     int32_t i = l * 16;
@@ -220,10 +223,10 @@ __device__ __forceinline__ void for_each_unit(const uint8_t* src, int32_t n16, i
 constexpr int kRep0 = 16, kRep0Stride = 257;
 static_assert(1024 + 2048 + kRep0 * kRep0Stride * 4 <= kTabBytes, "order-0 replicas must fit the table region");
 __device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* rep) {
-    const int l = lane_id();
+    const int l = (int)threadIdx.x;  // both waves
     constexpr int R = kRep0;
-    for (int i = l; i < R * kRep0Stride; i += 64) rep[i] = 0;
-    WSYNC();
+    for (int i = l; i < R * kRep0Stride; i += kWgThreads) rep[i] = 0;
+    __syncthreads();
     uint32_t* my = rep + (l & (R - 1)) * kRep0Stride;
     const int32_t n16 = n & ~15;
     for_each_unit<false>(src, n16, l, [&](const uint4& v, int32_t, uint32_t) {
@@ -237,13 +240,13 @@ __device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* 
         }
     });
     if (n16 + l < n) atomicAdd(&my[src[n16 + l]], 1u);
-    WSYNC();
-    for (int j = l; j < 256; j += 64) {
+    __syncthreads();
+    for (int j = l; j < 256; j += kWgThreads) {
         uint32_t s = 0;
         for (int r = 0; r < R; r++) s += rep[r * kRep0Stride + j];
         cnt[j] = s;
     }
-    WSYNC();
+    __syncthreads();
 }
 
 // order-1 pair counts: cnt[row(prev)*stride + col(cur)] with prev = 0 before the first byte
@@ -252,13 +255,13 @@ __device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* 
 // machine code the wide-alphabet path runs is then the code every small-alphabet block has already exercised.
 __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n, uint32_t* cnt, int stride, const uint8_t* dmap, uint32_t* rep,
                         int R, int rstride, int cells) {
-    const int l = lane_id();
+    const int l = (int)threadIdx.x;  // both waves; cnt has been zeroed (and that made visible) by the caller
     uint32_t* my = cnt;
     if (R > 1) {
-        for (int i = l; i < R * rstride; i += 64) rep[i] = 0;
+        for (int i = l; i < R * rstride; i += kWgThreads) rep[i] = 0;
         my = rep + (l & (R - 1)) * rstride;
     }
-    WSYNC();
+    __syncthreads();
     const int32_t n16 = n & ~15;
     for_each_unit<true>(src, n16, l, [&](const uint4& v, int32_t, uint32_t prev) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -283,14 +286,14 @@ __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n,
             atomicAdd(&my[(uint32_t)dmap[c]], 1u);
         }
     }
-    WSYNC();
+    __syncthreads();
     if (R > 1) {
-        for (int j = l; j < cells; j += 64) {
+        for (int j = l; j < cells; j += kWgThreads) {
             uint32_t s = 0;
             for (int r = 0; r < R; r++) s += rep[r * rstride + j];
             cnt[j] += s;
         }
-        WSYNC();
+        __syncthreads();
     }
 }
 
@@ -300,10 +303,10 @@ __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n,
 // global table cnt[cells].
 __device__ __attribute__((noinline)) void hist_o1_packed16(const uint8_t* src, int32_t n, uint32_t* cnt, int stride, const uint8_t* dmap,
                                                            uint32_t* w, int cells) {
-    const int l = lane_id();
+    const int l = (int)threadIdx.x;  // both waves
     const int words = (cells + 1) >> 1;
-    for (int i = l; i < words; i += 64) w[i] = 0;
-    WSYNC();
+    for (int i = l; i < words; i += kWgThreads) w[i] = 0;
+    __syncthreads();
     auto bump = [&](uint32_t idx) { atomicAdd(&w[idx >> 1], 1u << (16u * (idx & 1u))); };
     const int32_t n16 = n & ~15;
     for_each_unit<true>(src, n16, l, [&](const uint4& v, int32_t, uint32_t prev) {
@@ -324,9 +327,9 @@ __device__ __attribute__((noinline)) void hist_o1_packed16(const uint8_t* src, i
         const int32_t q = n >> 2;
         for (int k = 1; k < 4; k++) bump((uint32_t)dmap[src[k * q]]);
     }
-    WSYNC();
-    for (int i = l; i < cells; i += 64) cnt[i] = (w[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-    WSYNC();
+    __syncthreads();
+    for (int i = l; i < cells; i += kWgThreads) cnt[i] = (w[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1117,33 +1120,36 @@ __device__ __attribute__((noinline)) int32_t stream_o1_global(Blk B, int32_t tab
     return encode_stream<MODE_O1_GLOBAL>(B.src, B.n, ent, stride, B.slot + B.cap, B.cap - 9 - tab_len, B.prof);
 }
 
-// ---- phases 1 and 2, helper wave only ----
+// ---- phases 1 and 2: both waves count, the helper wave alone builds the tables (its result is the one that counts) ----
 __device__ __attribute__((noinline)) Prep prep_o0(Blk B) {
     const int l = lane_id();
+    const bool helper = wave_id() == 1;
     EncFixedLds* L = &lds;
     uint8_t* tab = lds.tab;
     uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);    // 256 words
     uint2* ent0 = reinterpret_cast<uint2*>(tab + 1024);  // 256 x 8 B
     uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
     hist_o0(B.src, B.n, cnt0, rep0);
+    Prep r{MODE_O0, 256, 1024, 0, 0};
+    if (!helper) return r;
     for (int i = l; i < 256; i += 64) L->syml[i] = (uint8_t)i;
     WSYNC();
-    Prep r{MODE_O0, 256, 1024, 0, 0};
     r.tab_len = tables_o0(cnt0, ent0, B.n, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
     if (9 + r.tab_len + 16 > B.cap) r.status = CRAMGPU_E_INSUFFICIENT;
     return r;
 }
 
-// Order 1: counts and packed symbols over the dense alphabet, in the LDS table region when 12 bytes per cell fit, else
-// in the workgroup's global scratch (same layout, same code: hist_o1 / tables_o1 take generic pointers).
+// Order 1: packed symbols over the dense alphabet in the LDS table region and pair counts in the spare area when they
+// fit, else both in the workgroup's global scratch (same layout, same code: hist_o1 / tables_o1 take generic pointers).
 __device__ __attribute__((noinline)) Prep prep_o1(Blk B) {
     const int l = lane_id();
+    const bool helper = wave_id() == 1;
     EncFixedLds* L = &lds;
     uint8_t* tab = lds.tab;
     uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);
     uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
     hist_o0(B.src, B.n, cnt0, rep0);
-    // dense alphabet = present symbols plus 0 (context 0 always exists)
+    // dense alphabet = present symbols plus 0 (context 0 always exists); both waves derive its size, one writes the maps
     uint32_t present = 0, mine = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1154,19 +1160,20 @@ __device__ __attribute__((noinline)) Prep prep_o1(Blk B) {
     }
     uint32_t nsym;
     uint32_t di = wave_excl_scan(mine, nsym);
-    WSYNC();
+    if (helper) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int jj = l * 4 + k;
-        if (present & (1u << k)) {
-            L->dmap[jj] = (uint8_t)di;
-            L->syml[di] = (uint8_t)jj;
-            di++;
-        } else {
-            L->dmap[jj] = 0;
+        for (int k = 0; k < 4; k++) {
+            int jj = l * 4 + k;
+            if (present & (1u << k)) {
+                L->dmap[jj] = (uint8_t)di;
+                L->syml[di] = (uint8_t)jj;
+                di++;
+            } else {
+                L->dmap[jj] = 0;
+            }
         }
     }
-    WSYNC();
+    __syncthreads();  // maps written, cnt0 read by both waves: the table region can be reused
     const int ns = (int)nsym;
     const int stride = ns | 1;
     const int cells = ns * stride;
@@ -1195,13 +1202,13 @@ __device__ __attribute__((noinline)) Prep prep_o1(Blk B) {
     if (packed) {
         hist_o1_packed16(B.src, B.n, cnt, stride, L->dmap, reinterpret_cast<uint32_t*>(big), cells);
     } else {
-        for (int i = l; i < cells; i += 64) cnt[i] = 0;
+        for (int i = (int)threadIdx.x; i < cells; i += kWgThreads) cnt[i] = 0;
         if (!in_lds) __threadfence();  // the scratch was another block's a moment ago: write back / invalidate around each phase
-        WSYNC();
-        hist_o1(B.src, B.n, cnt, stride, L->dmap, rep, R, rstride, cells);
+        hist_o1(B.src, B.n, cnt, stride, L->dmap, rep, R, rstride, cells);  // begins with a workgroup barrier
     }
     if (!in_lds) __threadfence();
-    WSYNC();
+    __syncthreads();
+    if (!helper) return r;
     if (in_lds) {
         r.tab_len = tables_o1(cnt, ent, ns, ns, stride, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
     } else {
@@ -1241,14 +1248,14 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
         uint8_t* pend = slot + cap;
         Blk B{a.in + d.in_off, slot, gs, a.rcp_tab, a.prof ? a.prof + 8 * (size_t)b : nullptr, n, cap};
         const long long t0 = PROF_ON(a.prof) ? clock64() : 0;
-        if (helper) {  // phases 1 and 2; the chain wave waits at the barrier below
+        {  // phases 1 and 2: both waves count, the helper wave builds the tables while the chain wave waits below
             Prep p;
             if (order == 0) {
                 p = prep_o0(B);
             } else {
                 p = prep_o1(B);
             }
-            if (l == 0) {
+            if (helper && l == 0) {
                 L->mode = p.mode;
                 L->stride = p.stride;
                 L->ent_off = p.ent_off;
