@@ -84,6 +84,7 @@ SYMBOLS = {
     "cramgpu_rans_uncompress": (I32, [P, I32, P, I32]),
     "cramgpu_rans_raw_size": (I32, [P, I32]),
     "cramgpu_rans_encode_dev": (I32, [P, P, P, P, I32, P, P, P]),
+    "cramgpu_rans_encode_static": (I32, [P, P, P, P, I32, P, P, P]),
     "cramgpu_rans_decode_dev": (I32, [P, P, P, P, I32, P, P]),
     "cramgpu_gather_dev": (I32, [P, P, P, P, I32, I32, I32, P, I64, P, P]),
     "cramgpu_rans_encode_batch": (I32, [P, P, I64, P, I64, P, I32, P]),

@@ -12,6 +12,18 @@
 
 #include "internal.h"
 
+// ---- scratch of cramgpu_rans_encode_static: device memory the library never allocates (include/cramgpu.h) ----
+// Layout: [0, 256) work-queue ticket | [256, 256 + 16 KiB) longest-first permutation of up to 4096 blocks |
+// kStaticGroups per-workgroup table areas (order-1 tables of alphabets too wide for LDS).  Every GPU the process uses
+// holds its own copy of this array until the process ends; in host code the name is only a handle for
+// hipGetSymbolAddress (cramgpu_open), kernels and memsets get the per-device address kept in the context.
+constexpr int kStaticGroups = 32;
+constexpr int kStaticMaxBlocks = 4096;
+constexpr size_t kStaticPermOff = 256;
+constexpr size_t kStaticGsOff = kStaticPermOff + (size_t)kStaticMaxBlocks * sizeof(int32_t);
+constexpr size_t kStaticBytes = kStaticGsOff + (size_t)kStaticGroups * ENC_GSCRATCH_BYTES;
+static __device__ __align__(256) uint8_t scratch[kStaticBytes];
+
 namespace {
 
 thread_local std::string g_err;
@@ -139,6 +151,7 @@ struct cramgpu_ctx {
     hipEvent_t last_use = nullptr;
     hipStream_t last_stream = nullptr;
     bool last_valid = false;
+    uint8_t* static_scratch = nullptr;  // this device's address of `scratch` (cramgpu_rans_encode_static)
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
@@ -183,8 +196,7 @@ int enter(cramgpu_ctx* c, hipStream_t s) {
     return 0;
 }
 int leave(cramgpu_ctx* c, hipStream_t s) {
-    if (!c->last_use) HIPCHK(hipEventCreateWithFlags(&c->last_use, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(c->last_use, s));
+    HIPCHK(hipEventRecord(c->last_use, s));  // created by cramgpu_open
     c->last_stream = s;
     c->last_valid = true;
     return 0;
@@ -371,6 +383,14 @@ cramgpu_ctx* cramgpu_open(int32_t device_index) {
               c->d_err.reserve(16) == hipSuccess && c->d_total.reserve(16) == hipSuccess &&
               c->h_total.reserve(16) == hipSuccess;
     if (ok) ok = launch_rcp_init(c->rcp_tab.p, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+    // the event that orders calls on different streams, and this device's address of the static scratch, up front: the
+    // allocation-free entry point creates and looks up nothing
+    if (ok) ok = hipEventCreateWithFlags(&c->last_use, hipEventDisableTiming) == hipSuccess;
+    if (ok) {
+        void* p = nullptr;
+        ok = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) == hipSuccess && p != nullptr;
+        c->static_scratch = static_cast<uint8_t*>(p);
+    }
     if (!ok) {
         fail(CRAMGPU_E_HIP, "cramgpu_open: allocation or init kernel failed", hipGetLastError());
         cramgpu_close(c);
@@ -428,6 +448,40 @@ int32_t cramgpu_rans_encode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_
     if (int rc = enter(c, s)) return rc;
     CallScope scope{c, s};
     return rans_run(c, c->res, true, d_in, d_out, blocks, n, d_out_len, d_out_pos, s);
+}
+
+int32_t cramgpu_rans_encode_static(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks,
+                                   int32_t n, int32_t* d_out_len, int64_t* d_out_pos, void* stream) {
+    if (!c || n < 0 || (n > 0 && (!d_in || !d_out || !d_blocks || !d_out_len || !d_out_pos)))
+        return fail(CRAMGPU_E_ARG, "cramgpu_rans_encode_static: bad argument");
+    if (n > kStaticMaxBlocks)
+        return fail(CRAMGPU_E_ARG, "cramgpu_rans_encode_static: at most 4096 blocks per call (the static scratch holds no more)");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    // everything below works on this device's copy of the static array, through the address taken at cramgpu_open
+    uint8_t* base = c->static_scratch;
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(base);
+    int32_t* perm = reinterpret_cast<int32_t*>(base + kStaticPermOff);
+    HIPCHK(hipMemsetAsync(base, 0, kStaticPermOff, s));  // the ticket must start at zero; the rest is rebuilt per call
+    HIPCHK(launch_lpt_perm(d_blocks, n, perm, s));
+    RansArgs a{};
+    a.in = d_in;
+    a.out = d_out;
+    a.desc = d_blocks;
+    a.perm = perm;
+    a.n_blocks = n;
+    a.out_len = d_out_len;
+    a.out_pos = d_out_pos;
+    a.ticket = ticket;
+    a.rcp_tab = c->rcp_tab.p;
+    a.tab_bytes = c->tab_bytes;
+    a.prof = nullptr;
+    a.gscratch = base + kStaticGsOff;
+    HIPCHK(launch_rans_encode(a, std::min(n, kStaticGroups), c->enc_lds, s));
+    return 0;
 }
 
 int32_t cramgpu_rans_decode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,

@@ -49,6 +49,7 @@ struct RansArgs {
 hipError_t launch_rans_encode(const RansArgs& a, int n_groups, size_t lds_bytes, hipStream_t s);  // 2-wave groups
 hipError_t launch_rans_decode(const RansArgs& a, int n_waves, size_t lds_bytes, hipStream_t s);
 hipError_t launch_rcp_init(uint32_t* d_rcp_tab, hipStream_t s);
+hipError_t launch_lpt_perm(const cramgpu_block* d_desc, int32_t n, int32_t* d_perm, hipStream_t s);  // n <= 4096
 size_t rans_encode_fixed_lds();
 size_t rans_decode_fixed_lds();
 hipError_t launch_gather(const uint8_t* src, const int64_t* pos, const int32_t* len, int32_t n, int32_t align,

@@ -1238,6 +1238,8 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
     int64_t pos = d.out_off;
     if (order != 0 && order != 1) {
         result = CRAMGPU_E_ORDER;
+    } else if (d.in_off < 0 || d.out_off < 0 || (d.in_off & (CRAMGPU_ARENA_ALIGN - 1)) || (d.out_off & (CRAMGPU_ARENA_ALIGN - 1))) {
+        result = CRAMGPU_E_ARG;  // the host checks this where it sees the descriptors; device-built tables are checked here
     } else if (n == 0) {
         result = 0;  // RANS#compress L61-62: EMPTY_BUFFER
     } else if (n < 0 || cap < 9 + 2 + 16) {
@@ -1323,7 +1325,7 @@ __global__ __launch_bounds__(128) void rans_encode_kernel(RansArgs a) {
         const uint32_t t = (uint32_t)UNIFORM(L->ticket);
         __syncthreads();  // both waves hold the ticket before the helper can draw the next one
         if (t >= (uint32_t)a.n_blocks) break;  // every workgroup reaches this: the queue only grows
-        encode_block(a, a.perm[t], gs);
+        encode_block(a, a.perm ? a.perm[t] : (int)t, gs);  // no permutation: blocks in table order
     }
 }
 
@@ -1347,6 +1349,44 @@ size_t rans_encode_fixed_lds() { return 0; }  // the encoder's LDS is static
 hipError_t launch_rans_encode(const RansArgs& a, int n_groups, size_t lds_bytes, hipStream_t s) {
     (void)lds_bytes;
     hipLaunchKernelGGL(rans_encode_kernel, dim3(n_groups), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+// Longest-processing-time order of up to kLptMax blocks on the device (the host does this with std::stable_sort where it
+// sees the descriptors): bitonic sort of (0x7FFFFFFF - length, index) keys in LDS by one workgroup.
+namespace {
+constexpr int kLptMax = 4096;
+__global__ __launch_bounds__(1024) void lpt_perm_kernel(const cramgpu_block* desc, int32_t n, int32_t* perm) {
+    __shared__ unsigned long long key[kLptMax];
+    for (int i = threadIdx.x; i < kLptMax; i += blockDim.x) {
+        unsigned long long k = ~0ull;  // padding sorts last
+        if (i < n) {
+            const int32_t len = desc[i].in_len;
+            k = ((unsigned long long)(0x7FFFFFFFu - (uint32_t)(len > 0 ? len : 0)) << 32) | (uint32_t)i;
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= kLptMax; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < kLptMax / 2; t += blockDim.x) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = key[lo], b = key[hi];
+                if ((a > b) == up) {
+                    key[lo] = b;
+                    key[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) perm[i] = (int32_t)(uint32_t)key[i];
+}
+}  // namespace
+
+hipError_t launch_lpt_perm(const cramgpu_block* d_desc, int32_t n, int32_t* d_perm, hipStream_t s) {
+    if (n > kLptMax) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lpt_perm_kernel, dim3(1), dim3(1024), 0, s, d_desc, n, d_perm);
     return hipGetLastError();
 }
 

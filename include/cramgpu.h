@@ -102,6 +102,20 @@ typedef struct {
 int32_t cramgpu_rans_encode_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,
                                 int32_t n_blocks, int32_t* d_out_len, int64_t* d_out_pos, void* stream);
 
+/* cramgpu_rans_encode_dev for callers that cannot allocate device memory: code running under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (a JVM allocates freely).
+ * Same arenas, same results and same d_out_len / d_out_pos as cramgpu_rans_encode_dev, with two differences:
+ *   - d_blocks is a DEVICE array of descriptors (the host table would need a staged upload);
+ *   - the kernels' scratch (work-queue ticket, longest-first permutation, per-workgroup order-1 tables of wide
+ *     alphabets) lives in a static device array of the library (about 24.6 MiB per GPU, held until the process ends)
+ *     instead of buffers grown with hipMalloc: the call allocates nothing, frees nothing and creates nothing.
+ * Limit: n_blocks <= 4096 per call (CRAMGPU_E_ARG beyond); at most 32 workgroups run the batch, so it suits one or a
+ * few containers per call, not a whole read set.  All calls on one GPU share the one array: calls that overlap on a
+ * GPU (different contexts or processes' streams on the same device) race; calls on one context are ordered by the
+ * library as every other call is.  Stream-ordered, does not synchronise. */
+int32_t cramgpu_rans_encode_static(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks,
+                                   int32_t n_blocks, int32_t* d_out_len, int64_t* d_out_pos, void* stream);
+
 /* Device-resident batch decode: block b's raw bytes land at d_out[blocks[b].out_off ..); d_out_len[b] = raw size
  * or a negative code. */
 int32_t cramgpu_rans_decode_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,

@@ -174,7 +174,7 @@ using std::min;
 
 // ---- runtime API ----
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
@@ -191,6 +191,9 @@ inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); 
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+#define HIP_SYMBOL(x) (&(x))
+template <class T>
+inline hipError_t hipGetSymbolAddress(void** p, T* sym) { *p = (void*)sym; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
