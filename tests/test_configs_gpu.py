@@ -1,0 +1,194 @@
+"""BASELINE.json configs[3] and configs[4] at their defining shapes ("configs_untested").
+
+configs[4]  lossy model R8-N40-D8 + order-1 rANS on 10 kbp reads with a high indel rate:
+            (a) a container of 200 reads x 10 kbp (3 % substitutions, 4 % insertions, 4 % deletions) through
+                K3 -> K5 -> merge, every column against the oracle;
+            (b) one > 100 MB order-1 block and one 100 MB order-0 block — the size of that config's QS block —
+                byte for byte against the oracle's stream, and back (32-bit counters at 10^8, double normalisation at
+                large T, cramgpu_rans_bound near 105 MB).
+configs[3]  the per-GPU shard shape of the 600 M-read run: 2000 containers over a 4-contig reference arena (non-zero
+            ref_off per window), block / base arenas beyond 2^31 bytes, through bench.Step / DecodeStep: round trip of
+            every block and read, oracle equality for the first and last container of every contig.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _long_read_container(rng, n, L, ref):
+    """n start-sorted reads of about L bases: match runs cut by insertions / deletions of 1-3 bases, substitutions in
+    the match runs, uniform qualities 1-30."""
+    ref_len = ref.size
+    starts = np.sort(rng.integers(1, ref_len - 2 * L, n))
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    cigars, bases, quals = [], [], []
+    for r in range(n):
+        rp = int(starts[r]) - 1
+        out, cg, left = [], [], L
+        while left > 0:
+            run = int(min(left, rng.geometric(0.08)))
+            seg = ref[rp:rp + run].copy()
+            sub = rng.random(run) < 0.03
+            seg[sub] = acgt[(np.searchsorted(acgt, seg[sub]) + rng.integers(1, 4, int(sub.sum()))) % 4]
+            out.append(seg)
+            cg.append((run << 4) | 0)
+            rp += run
+            left -= run
+            if left <= 0:
+                break
+            k = int(rng.integers(1, 4))
+            if rng.random() < 0.5:
+                k = min(k, left)
+                out.append(rng.choice(acgt, k))
+                cg.append((k << 4) | 1)
+                left -= k
+            else:
+                cg.append((k << 4) | 2)
+                rp += k
+        if (cg[-1] & 15) != 0:  # end on a match run, as aligners do
+            out.append(ref[rp:rp + 5].copy())
+            cg.append((5 << 4) | 0)
+        b = np.concatenate(out)
+        cigars.append(cg)
+        bases.append(b.tobytes())
+        quals.append(rng.integers(1, 31, b.size, dtype=np.uint8).tobytes())
+    return starts, cigars, bases, quals
+
+
+def test_config5_long_reads_lossy_pipeline(orc):
+    import torch
+    from cramtools_amd import external_compression as xc
+    from cramtools_amd import records
+    rng = np.random.default_rng(2024)
+    n, L = 200, 10000
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), 2_300_000)
+    starts, cigars, bases, quals = _long_read_container(rng, n, L, ref)
+    mapq = np.where(rng.random(n) < 0.05, 0, 60).astype(np.uint8)
+    o_reads = orc.Reads(starts, cigars, bases, quals=quals, mapq=mapq)
+    assert int(o_reads.n_cigar.min()) > 500  # the config's "thousands of features per read"
+    eng = xc.Engine(0)
+    try:
+        reads = records.ReadBatch.from_lists(DEV, starts, cigars, bases, quals=quals, mapq=mapq, ref_len=ref.size)
+        d_ref = torch.as_tensor(np.concatenate([ref, np.zeros(16, np.uint8)])).to(DEV)
+        fac = records.Sam2CramRecordFactory(eng)
+        fac.set_ref_bases(d_ref)
+        feats, hist = fac.create_variations(reads, feature_cap=n * L // 4)
+        want = orc.extract_features(o_reads, ref)
+        got = feats.to_host()
+        for key in ("off", "op", "pos", "a", "b"):
+            assert np.array_equal(got[key], want[key]), key
+        assert np.array_equal(hist[0], want["hist"])
+        m = records.substitution_matrix(hist[0])
+        assert np.array_equal(m, orc.substitution_matrix(want["hist"]))
+        fac.assign_codes(reads, feats, m)
+        orc.assign_codes(want, m)
+        assert np.array_equal(feats.to_host()["a"], want["a"])
+        # K5 under the config's policy (and its CLI-runnable spelling with the no-op X0 term), then the merge
+        for spec in ("R8-N40-D8", "R8-N40-D8-X0", "N40-D8"):  # the last one leaves reads unforced: Q features to merge
+            qsp = records.QualityScorePreservation(eng, spec)
+            pols = orc.parse_policies(spec)
+            wpos = qsp.tracks_windows(starts, o_reads.aln_span, o_reads.rflags, mapq, ref.size)
+            assert np.array_equal(wpos, orc.tracks_windows(o_reads, pols, ref.size))
+            scores, force, status = qsp.add_quality_scores(reads, d_ref, wpos)
+            ws, wf, wst = orc.lossy_quals(o_reads, ref, pols, 1000000, wpos)
+            assert np.array_equal(status.cpu().numpy(), wst) and (wst == 0).all()
+            assert np.array_equal(force.cpu().numpy(), wf)
+            tot = int(o_reads.read_len.sum())
+            assert np.array_equal(scores.cpu().numpy()[:tot], ws[:tot])
+            merged = qsp.merge_quality_features(reads, scores, force, status, feats)
+            wm = orc.merge_quality_features(o_reads, ws, wf, wst, want)
+            gm = merged.to_host()
+            for key in ("off", "op", "pos", "a", "b"):
+                assert np.array_equal(gm[key], wm[key]), (spec, key)
+    finally:
+        eng.close()
+
+
+def test_config5_100mb_blocks(orc):
+    """The QS block of a 10 000 x 10 kbp container is one ~100 MB rANS stream: encode and decode one order-1 and one
+    order-0 block of that size and compare both directions with the oracle (E14#compress L13-86,
+    Frequencies#calcFrequencies_o1 L149-193)."""
+    from cramtools_amd import external_compression as xc
+    rng = np.random.default_rng(5)
+    lut = np.array([0, 1] + [6] * 8 + [15] * 10 + [22] * 5 + [27] * 5 + [33], np.uint8)  # Illumina-8 bins of 0..30
+    q = rng.integers(1, 31, 100_000_003, dtype=np.uint8)  # uniform 1-30, odd tail
+    binned = lut[q]
+    keep = rng.random(q.size) < 0.1  # N40: mismatching bases keep their score
+    o1 = np.where(keep, q, binned).astype(np.uint8).tobytes()
+    o0 = q[:100_000_000].tobytes()
+    assert xc.rans_bound(len(o1)) == int(1.05 * len(o1) + 257 * 257 * 3 + 4)
+    eng = xc.Engine(0)
+    try:
+        outs = eng.compress_many([o1, o0], [1, 0])
+        w1, w0 = orc.rans(o1, 1), orc.rans(o0, 0)
+        assert len(outs[0]) == len(w1) and outs[0] == w1
+        assert len(outs[1]) == len(w0) and outs[1] == w0
+        back = eng.uncompress_many([w1, w0])
+        assert back[0] == o1 and back[1] == o0
+    finally:
+        eng.close()
+
+
+def test_config4_shard_shape(orc):
+    import torch
+    import bench
+    from cramtools_amd import external_compression as xc
+    n_contigs, n_reads, ref_len = 4, 20_000_000, 64_000_000
+    eng = xc.Engine(0)
+    try:
+        w = bench.build_workload(DEV, n_reads, ref_len, 150, 0, lambda r, ref: bench.gpu_insert_bases(eng, r, ref, n_reads),
+                                 n_contigs=n_contigs)
+        assert w["n_cont"] == 2000 and w["d_in"].numel() > 2 ** 31 and w["out_bytes"] > 2 ** 31
+        assert w["reads"].bases.numel() > 2 ** 31
+        wins = w["reads"].win.cpu().numpy().reshape(-1, 3)
+        assert len(set(wins[:, 0].tolist())) == n_contigs and wins[-1, 0] > 0
+        step = bench.Step(DEV, eng, w)
+        step.run(True)
+        lens = step.d_len.cpu().numpy()
+        pos = step.d_pos.cpu().numpy()
+        assert (lens > 0).all()
+        assert int(pos.max()) > 2 ** 31  # streams beyond the 32-bit range of their arena
+        ns = len(bench.SERIES)
+        per = w["n_cont"] // n_contigs
+        reads = w["reads"]
+        ref_h = w["ref"].cpu().numpy()
+        for c in sorted({k * per for k in range(n_contigs)} | {k * per + per - 1 for k in range(n_contigs)}):
+            # the container's ten rANS blocks against the oracle
+            for i in range(c * ns, (c + 1) * ns):
+                b = w["blocks"][i]
+                raw = w["d_in"][b.in_off:b.in_off + b.in_len].cpu().numpy().tobytes()
+                got = step.d_out[int(pos[i]):int(pos[i]) + int(lens[i])].cpu().numpy().tobytes()
+                assert got == orc.rans(raw, b.order), (c, i)
+            # and its features (K3 against the contig-local window)
+            r0, r1 = c * bench.READS_PER_CONTAINER, (c + 1) * bench.READS_PER_CONTAINER
+
+            class R:
+                pass
+            r = R()
+            r.n = r1 - r0
+            b0 = int(reads.base_off[r0].item())
+            c0 = int(reads.cigar_off[r0].item())
+            c1 = int(reads.cigar_off[r1 - 1].item()) + int(reads.n_cigar[r1 - 1].item())
+            r.base_off = np.ascontiguousarray(reads.base_off[r0:r1].cpu().numpy() - b0)
+            r.cigar_off = np.ascontiguousarray(reads.cigar_off[r0:r1].cpu().numpy() - c0)
+            for k in ("read_len", "aln_start", "rflags", "n_cigar"):
+                setattr(r, k, np.ascontiguousarray(getattr(reads, k)[r0:r1].cpu().numpy()))
+            r.bases = np.ascontiguousarray(reads.bases[b0:b0 + r.n * 150 + 16].cpu().numpy())
+            r.cigar = np.ascontiguousarray(reads.cigar[c0:c1 + 1].cpu().numpy().view(np.uint32))
+            woff, wlen = int(wins[c, 0]), int(wins[c, 1])
+            want = orc.extract_features(r, ref_h[woff:woff + wlen])
+            f0, f1 = int(step.feats.off[r0].item()), int(step.feats.off[r1].item())
+            assert np.array_equal(step.feats.off[r0:r1 + 1].cpu().numpy() - f0, want["off"]), c
+            assert np.array_equal(step.feats.op[f0:f1].cpu().numpy(), want["op"]), c
+            assert np.array_equal(step.feats.pos[f0:f1].cpu().numpy(), want["pos"]), c
+            assert np.array_equal(step.feats.a[f0:f1].cpu().numpy() & 0xFFFF, want["a"] & 0xFFFF), c
+        dec = bench.DecodeStep(DEV, eng, w, step)
+        dec.prepare()
+        dec.run(True)
+        assert "round-trip" in dec.verify()
+    finally:
+        eng.close()
+        torch.cuda.empty_cache()
