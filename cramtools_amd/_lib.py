@@ -66,6 +66,29 @@ class Features(C.Structure):
                 ("cap", C.c_int64)]
 
 
+class HostReads(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_cont", C.c_int32), ("n_bases", C.c_int64), ("n_cigar_ops", C.c_int64),
+                ("bases", C.c_void_p), ("quals", C.c_void_p), ("read_len", C.c_void_p), ("aln_start", C.c_void_p),
+                ("rflags", C.c_void_p), ("mapq", C.c_void_p), ("cigar", C.c_void_p), ("n_cigar", C.c_void_p),
+                ("cont_reads", C.c_void_p), ("cont_contig", C.c_void_p)]
+
+
+class HostReadResults(C.Structure):
+    _fields_ = [("feats", Features), ("matrices", C.c_void_p), ("sub_hist", C.c_void_p), ("scores", C.c_void_p),
+                ("force", C.c_void_p), ("status", C.c_void_p)]
+
+
+class HostRecords(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_cont", C.c_int32), ("n_seq", C.c_int64), ("read_len", C.c_void_p),
+                ("aln_start", C.c_void_p), ("rflags", C.c_void_p), ("cont_reads", C.c_void_p), ("cont_contig", C.c_void_p),
+                ("cont_win_start0", C.c_void_p), ("cont_win_len", C.c_void_p), ("feats", Features), ("seq", C.c_void_p),
+                ("seq_off", C.c_void_p), ("matrices", C.c_void_p), ("default_qs", C.c_int32), ("reserved", C.c_int32)]
+
+
+class HostRestoreResults(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("scores", C.c_void_p), ("status_bases", C.c_void_p), ("status_quals", C.c_void_p)]
+
+
 class Policy(C.Structure):
     _fields_ = [("read_cat", C.c_int32), ("read_param", C.c_int32), ("treatment", C.c_int32), ("n_base_cat", C.c_int32),
                 ("base_cat", C.c_int32 * 8), ("base_param", C.c_int32 * 8)]
@@ -104,6 +127,10 @@ SYMBOLS = {
     "cramgpu_lossy_quals_dev": (I32, [P, P, P, P, I32, P, I32, P, P, P, P]),
     "cramgpu_tracks_windows": (I32, [I32, P, P, P, P, P, I32, I64, I32, P, P]),
     "cramgpu_merge_quality_features_dev": (I64, [P, I32, P, P, P, P, P, P, P, P]),
+    "cramgpu_ref_upload": (I32, [P, I32, P, I64]),
+    "cramgpu_ref_drop": (I32, [P, I32]),
+    "cramgpu_submit_reads": (P, [P, P, C.c_char_p, I32, P]),
+    "cramgpu_submit_restore": (P, [P, P, P]),
 }
 
 _lib = None

@@ -113,11 +113,27 @@ struct LaunchRes {
     }
 };
 
+// What the second half of a record job (once the feature count is on the host) still has to copy back.
+struct CopyBack {
+    void* dst;
+    const void* src;
+    size_t bytes;     // fixed size, or per-feature size when per_feature
+    bool per_feature;
+};
+
 struct cramgpu_job {
     LaunchRes res;
     hipStream_t stream = nullptr;
     cramgpu_ctx* ctx = nullptr;
     bool busy = false, decode = false, fetched = false;
+    int kind = 0;                 // 0 rANS blocks, 1 cramgpu_submit_reads, 2 cramgpu_submit_restore
+    DevBuf<uint8_t> arena;        // record jobs: every device buffer of the job, carved out of one allocation
+    PinBuf<uint8_t> pin;          // record jobs: small host-built tables on their way up, the feature count on its way down
+    std::vector<CopyBack> back;   // record jobs: results to copy once the count is known
+    int64_t* h_total = nullptr;   // in pin
+    int64_t feat_cap = 0;
+    int64_t* h_feat_count = nullptr;  // caller's feats.off[n_reads]
+    int32_t early_rc = 0;         // verdict known at submit time (reported by wait)
     int32_t n = 0;
     uint8_t* out_arena = nullptr;
     int32_t* out_len = nullptr;
@@ -152,6 +168,13 @@ struct cramgpu_ctx {
     hipStream_t last_stream = nullptr;
     bool last_valid = false;
     uint8_t* static_scratch = nullptr;  // this device's address of `scratch` (cramgpu_rans_encode_static)
+    // reference contigs of the host-form level-2 calls (cramgpu_ref_upload) and their ReferenceTracks window positions
+    struct Contig {
+        DevBuf<uint8_t> d;
+        int64_t len = -1;
+        int64_t tracks_pos = 1;
+    };
+    std::vector<Contig> contigs;
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
@@ -413,7 +436,10 @@ void cramgpu_close(cramgpu_ctx* c) {
         if (sl.ev) (void)hipEventDestroy(sl.ev);
     }
     if (c->last_use) (void)hipEventDestroy(c->last_use);
+    for (auto& g : c->contigs) g.d.release();
     for (auto& j : c->jobs) {
+        j.arena.release();
+        j.pin.release();
         j.d_in.release(); j.d_out.release(); j.d_len.release(); j.d_pos.release(); j.h_len.release(); j.h_pos.release();
         j.res.release();
         if (j.stream) (void)hipStreamDestroy(j.stream);
@@ -623,6 +649,7 @@ cramgpu_job* cramgpu_rans_submit(cramgpu_ctx* c, int32_t decode, const uint8_t* 
           ok(j->d_len.reserve(n)) && ok(j->d_pos.reserve(n)) && ok(j->h_len.reserve(n)) && ok(j->h_pos.reserve(n))))
         return nullptr;
     j->ctx = c;
+    j->kind = 0;
     j->decode = decode != 0;
     j->fetched = false;
     j->n = n;
@@ -646,6 +673,20 @@ static int job_fetch(cramgpu_job* j) {
     cramgpu_ctx* c = j->ctx;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventSynchronize(j->coded));
+    if (j->kind != 0) {  // record job: the feature count is on the host now, the results follow
+        const int64_t total = j->h_total ? *j->h_total : 0;
+        if (j->h_feat_count) *j->h_feat_count = total;
+        const bool fits = total <= j->feat_cap;
+        if (!fits && !j->early_rc) j->early_rc = fail(CRAMGPU_E_INSUFFICIENT, "record job: feature capacity too small (feats.off[n_reads] = capacity needed)");
+        for (const CopyBack& b : j->back) {
+            if (b.per_feature && !fits) continue;
+            const size_t bytes = b.per_feature ? b.bytes * (size_t)total : b.bytes;
+            if (bytes) HIPCHK(hipMemcpyAsync(b.dst, b.src, bytes, hipMemcpyDeviceToHost, j->stream));
+        }
+        HIPCHK(hipEventRecord(j->done, j->stream));
+        j->fetched = true;
+        return 0;
+    }
     for (int32_t i = 0; i < j->n; i++) {
         const int32_t len = j->h_len.p[i];
         j->out_len[i] = len;
@@ -681,6 +722,7 @@ int32_t cramgpu_job_wait(cramgpu_job* j) {
         const hipError_t e = hipEventSynchronize(j->done);
         if (e != hipSuccess) rc = fail(CRAMGPU_E_HIP, hipGetErrorString(e));
     }
+    if (!rc && j->kind != 0) rc = j->early_rc;
     j->busy = false;  // the slot (and its device buffers) can take the next submission
     return rc;
 }
@@ -766,7 +808,7 @@ int64_t cramgpu_extract_features_dev(cramgpu_ctx* c, const cramgpu_reads* reads,
     HIPCHK(c->d_list.reserve((size_t)n + 1));  // reads that have features + (last word) their number
     int32_t* list = c->d_list.p;
     uint32_t* list_n = reinterpret_cast<uint32_t*>(c->d_list.p + n);
-    if (n > 0) HIPCHK(launch_extract_features(*reads, d_ref, *feats, nullptr, c->d_counts.p, false, list, list_n, s));
+    if (n > 0) HIPCHK(launch_extract_features(*reads, d_ref, *feats, nullptr, c->d_counts.p, false, list, list_n, nullptr, s));
     HIPCHK(c->d_scan_ws.reserve(feature_scan_ws_elems(n)));
     HIPCHK(launch_feature_scan(n, c->d_counts.p, feats->off, c->d_total.p, c->d_scan_ws.p, s));
     HIPCHK(hipMemcpyAsync(c->h_total.p, c->d_total.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -774,7 +816,7 @@ int64_t cramgpu_extract_features_dev(cramgpu_ctx* c, const cramgpu_reads* reads,
     const int64_t total = c->h_total.p[0];
     if (total > feats->cap) return fail(CRAMGPU_E_INSUFFICIENT, "extract_features: feature capacity too small");
     if (n > 0 && total > 0)
-        HIPCHK(launch_extract_features(*reads, d_ref, *feats, d_sub_hist, c->d_counts.p, true, list, list_n, s));
+        HIPCHK(launch_extract_features(*reads, d_ref, *feats, d_sub_hist, c->d_counts.p, true, list, list_n, nullptr, s));
     return total;
 }
 
@@ -934,14 +976,14 @@ static bool host_read_gate(const cramgpu_policy& p, bool unmapped, int mapq) {
     }
 }
 
-// ReferenceTracks.ensureRange :127-133 / moveForwardTo :87-119 replayed in read order
-int32_t cramgpu_tracks_windows(int32_t n_reads, const int32_t* aln_start, const int32_t* aln_span, const uint8_t* rflags,
-                               const uint8_t* mapq, const cramgpu_policy* pol, int32_t n_pol, int64_t ref_len,
-                               int32_t window, int32_t* wpos, int32_t* throws_at) {
+// ReferenceTracks.ensureRange :127-133 / moveForwardTo :87-119 replayed in read order, from window position `position`
+// (1 for a fresh ReferenceTracks); *pos_out = the position afterwards.
+static int32_t tracks_windows_from(int32_t n_reads, const int32_t* aln_start, const int32_t* aln_span, const uint8_t* rflags,
+                                   const uint8_t* mapq, const cramgpu_policy* pol, int32_t n_pol, int64_t ref_len,
+                                   int32_t window, int64_t position, int32_t* wpos, int32_t* throws_at, int64_t* pos_out) {
     if (throws_at) *throws_at = -1;
     if (int rc = policies_supported(pol, n_pol)) return rc;
     const int64_t W = window < ref_len ? window : ref_len;
-    int64_t position = 1;
     for (int32_t r = 0; r < n_reads; r++) {
         wpos[r] = 0;
         if (rflags[r] & (CRAMGPU_RF_NULL_QUALS | CRAMGPU_RF_SKIP)) continue;
@@ -963,7 +1005,15 @@ int32_t cramgpu_tracks_windows(int32_t n_reads, const int32_t* aln_start, const 
         }
         wpos[r] = (int32_t)position;
     }
+    if (pos_out) *pos_out = position;
     return 0;
+}
+
+int32_t cramgpu_tracks_windows(int32_t n_reads, const int32_t* aln_start, const int32_t* aln_span, const uint8_t* rflags,
+                               const uint8_t* mapq, const cramgpu_policy* pol, int32_t n_pol, int64_t ref_len,
+                               int32_t window, int32_t* wpos, int32_t* throws_at) {
+    return tracks_windows_from(n_reads, aln_start, aln_span, rflags, mapq, pol, n_pol, ref_len, window, 1, wpos, throws_at,
+                               nullptr);
 }
 
 int32_t cramgpu_lossy_quals_dev(cramgpu_ctx* c, const cramgpu_reads* reads, const uint8_t* d_ref, const int32_t* d_wpos,
@@ -1003,7 +1053,7 @@ int64_t cramgpu_merge_quality_features_dev(cramgpu_ctx* c, int32_t n_reads, cons
     HIPCHK(c->d_counts.reserve((size_t)n_reads + 1));
     if (n_reads > 0)
         HIPCHK(launch_merge_quality(n_reads, d_read_len, d_base_off, d_scores, d_force, d_qstatus, *in, *out, c->d_counts.p,
-                                    false, s));
+                                    false, nullptr, s));
     HIPCHK(c->d_scan_ws.reserve(feature_scan_ws_elems(n_reads)));
     HIPCHK(launch_feature_scan(n_reads, c->d_counts.p, out->off, c->d_total.p, c->d_scan_ws.p, s));
     HIPCHK(hipMemcpyAsync(c->h_total.p, c->d_total.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -1012,8 +1062,470 @@ int64_t cramgpu_merge_quality_features_dev(cramgpu_ctx* c, int32_t n_reads, cons
     if (total > out->cap) return fail(CRAMGPU_E_INSUFFICIENT, "merge_quality_features: capacity too small");
     if (n_reads > 0 && total > 0)
         HIPCHK(launch_merge_quality(n_reads, d_read_len, d_base_off, d_scores, d_force, d_qstatus, *in, *out, c->d_counts.p,
-                                    true, s));
+                                    true, nullptr, s));
     return total;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Level 2, host form: record jobs over host stripes
+// =====================================================================================================
+namespace {
+
+// Device memory of a record job, carved out of one allocation: first pass measures, second pass hands out.
+struct Carver {
+    uint8_t* base;
+    size_t off = 0;
+    template <class T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+cramgpu_job* grab_job(cramgpu_ctx* c, int kind) {  // under c->mu
+    cramgpu_job* j = nullptr;
+    for (auto& cand : c->jobs)
+        if (!cand.busy) {
+            j = &cand;
+            break;
+        }
+    if (!j) {
+        fail(CRAMGPU_E_ARG, "submit: CRAMGPU_MAX_JOBS jobs outstanding, wait for one first");
+        return nullptr;
+    }
+    auto ok = [&](hipError_t e) { return e == hipSuccess || (fail(CRAMGPU_E_HIP, hipGetErrorString(e)), false); };
+    if (!ok(hipSetDevice(c->device))) return nullptr;
+    if (!j->coded && !(ok(hipEventCreateWithFlags(&j->coded, hipEventDisableTiming)) &&
+                       ok(hipEventCreateWithFlags(&j->done, hipEventDisableTiming)) &&
+                       ok(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking))))
+        return nullptr;
+    j->ctx = c;
+    j->kind = kind;
+    j->fetched = false;
+    j->early_rc = 0;
+    j->back.clear();
+    j->h_total = nullptr;
+    j->h_feat_count = nullptr;
+    j->feat_cap = 0;
+    return j;
+}
+
+// windows of the containers of a stripe: the whole contig, or the caller's region clipped to it.  The reference arena
+// argument of the record kernels is the null pointer and ref_off the contig's device ADDRESS: contigs are separate
+// allocations (uploaded at different times), and "arena + offset" is all the kernels do with the pair.
+int build_windows(cramgpu_ctx* c, int32_t n_cont, const int32_t* cont_contig, const int64_t* start0, const int64_t* len,
+                  cramgpu_refwin* out) {
+    for (int32_t k = 0; k < n_cont; k++) {
+        const int32_t id = cont_contig[k];
+        if (id < 0 || id >= (int32_t)c->contigs.size() || c->contigs[id].len < 0)
+            return fail(CRAMGPU_E_ARG, "record job: a container names a contig that was not uploaded (cramgpu_ref_upload)");
+        const auto& g = c->contigs[id];
+        int64_t s0 = 0, ln = g.len;
+        if (start0 && len) {
+            s0 = std::max<int64_t>(0, start0[k]);
+            ln = std::max<int64_t>(0, std::min<int64_t>(len[k], g.len - s0));
+        }
+        out[k] = cramgpu_refwin{(int64_t)(uintptr_t)(g.d.p + s0), ln, s0};
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cramgpu_ref_upload(cramgpu_ctx* c, int32_t contig, const uint8_t* bases, int64_t len) {
+    if (!c || contig < 0 || contig >= CRAMGPU_MAX_CONTIGS || len < 0 || (len > 0 && !bases))
+        return fail(CRAMGPU_E_ARG, "cramgpu_ref_upload: bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    for (auto& j : c->jobs)  // a job in flight may be reading the contig this call replaces
+        if (j.busy && j.kind != 0) HIPCHK(hipStreamSynchronize(j.stream));
+    if ((size_t)contig >= c->contigs.size()) c->contigs.resize((size_t)contig + 1);
+    auto& g = c->contigs[contig];
+    HIPCHK(g.d.reserve((size_t)len + 32));  // kernels read whole 16-byte units
+    if (len) HIPCHK(hipMemcpy(g.d.p, bases, (size_t)len, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(g.d.p + len, 0, 32));
+    g.len = len;
+    g.tracks_pos = 1;
+    return 0;
+}
+
+int32_t cramgpu_ref_drop(cramgpu_ctx* c, int32_t contig) {
+    if (!c || contig < 0) return fail(CRAMGPU_E_ARG, "cramgpu_ref_drop: bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if ((size_t)contig >= c->contigs.size() || c->contigs[contig].len < 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    for (auto& j : c->jobs)
+        if (j.busy && j.kind != 0) HIPCHK(hipStreamSynchronize(j.stream));
+    c->contigs[contig].d.release();
+    c->contigs[contig].len = -1;
+    return 0;
+}
+
+cramgpu_job* cramgpu_submit_reads(cramgpu_ctx* c, const cramgpu_host_reads* R, const char* lossy_spec, int32_t window,
+                                  cramgpu_host_read_results* out) {
+    if (!c || !R || !out || R->n_reads < 0 || R->n_cont < 1 || R->n_bases < 0 || R->n_cigar_ops < 0 || !R->cont_reads ||
+        !R->cont_contig || !out->feats.off || out->feats.cap < 0 || !out->matrices ||
+        (R->n_reads > 0 && (!R->bases || !R->read_len || !R->aln_start || !R->rflags || !R->cigar || !R->n_cigar)) ||
+        (out->feats.cap > 0 && (!out->feats.op || !out->feats.pos || !out->feats.a || !out->feats.b))) {
+        fail(CRAMGPU_E_ARG, "cramgpu_submit_reads: bad argument");
+        return nullptr;
+    }
+    const bool lossy = lossy_spec != nullptr;
+    if (lossy && (!R->quals || !R->mapq || !out->scores || !out->force || !out->status)) {
+        fail(CRAMGPU_E_ARG, "cramgpu_submit_reads: the lossy model needs quals, mapq and the scores / force / status outputs");
+        return nullptr;
+    }
+    const int32_t n = R->n_reads, nc = R->n_cont;
+    const int64_t nb = R->n_bases, ncg = R->n_cigar_ops, cap = out->feats.cap;
+    // host-side bookkeeping: container table, totals, longest read
+    std::vector<int32_t> cont_first((size_t)nc + 1, 0);
+    for (int32_t k = 0; k < nc; k++) {
+        if (R->cont_reads[k] < 0) {
+            fail(CRAMGPU_E_ARG, "cramgpu_submit_reads: negative container size");
+            return nullptr;
+        }
+        cont_first[k + 1] = cont_first[k] + R->cont_reads[k];
+    }
+    int64_t sum_len = 0, sum_cg = 0;
+    int32_t max_len = 0;
+    for (int32_t r = 0; r < n; r++) {
+        if (R->read_len[r] < 0 || R->n_cigar[r] < 0) {
+            fail(CRAMGPU_E_ARG, "cramgpu_submit_reads: negative read or CIGAR length");
+            return nullptr;
+        }
+        sum_len += R->read_len[r];
+        sum_cg += R->n_cigar[r];
+        max_len = std::max(max_len, R->read_len[r]);
+    }
+    if (cont_first[nc] != n || sum_len != nb || sum_cg != ncg) {
+        fail(CRAMGPU_E_ARG, "cramgpu_submit_reads: cont_reads / n_bases / n_cigar_ops do not add up");
+        return nullptr;
+    }
+    cramgpu_policy pol[64];
+    int32_t n_pol = 0;
+    if (lossy) {
+        n_pol = cramgpu_parse_policies(lossy_spec, pol, 64);
+        if (n_pol < 0) return nullptr;
+        if (policies_supported(pol, n_pol)) return nullptr;
+    }
+    if (window <= 0) window = 1000000;  // ReferenceTracks.java:23
+
+    std::lock_guard<std::mutex> lk(c->mu);
+    cramgpu_job* j = grab_job(c, 1);
+    if (!j) return nullptr;
+    hipStream_t s = j->stream;
+    auto ok = [&](hipError_t e) { return e == hipSuccess || (fail(CRAMGPU_E_HIP, hipGetErrorString(e)), false); };
+
+    // ---- pinned staging: windows, container table, policies, window positions, the count on its way back ----
+    const size_t pin_bytes = 256 + (size_t)nc * sizeof(cramgpu_refwin) + 256 + ((size_t)nc + 1) * 4 + 256 +
+                             sizeof(pol) + 256 + (lossy ? (size_t)n * 4 : 0) + 256;
+    if (!ok(j->pin.reserve(pin_bytes))) return nullptr;
+    Carver hp{j->pin.p};
+    j->h_total = hp.take<int64_t>(2);
+    j->h_total[0] = 0;
+    cramgpu_refwin* h_win = hp.take<cramgpu_refwin>(nc);
+    int32_t* h_first = hp.take<int32_t>((size_t)nc + 1);
+    cramgpu_policy* h_pol = hp.take<cramgpu_policy>(64);
+    int32_t* h_wpos = lossy ? hp.take<int32_t>(n) : nullptr;
+    if (build_windows(c, nc, R->cont_contig, nullptr, nullptr, h_win)) return nullptr;
+    memcpy(h_first, cont_first.data(), ((size_t)nc + 1) * 4);
+    if (lossy) {
+        memcpy(h_pol, pol, sizeof(pol));
+        // ReferenceTracks.ensureRange replayed container by container; a contig's window position carries over from
+        // one container (and one submission) to the next, as the writer's per-reference ReferenceTracks does
+        // (CRAMContainerStreamWriter.java:209-227)
+        std::vector<int32_t> span;
+        int64_t co = 0;  // CIGAR offset of the read at hand
+        for (int32_t k = 0; k < nc; k++) {
+            const int32_t r0 = cont_first[k], m = R->cont_reads[k];
+            span.assign((size_t)m, 0);
+            for (int32_t r = 0; r < m; r++) {
+                int64_t ref_len = 0;
+                for (int32_t e = 0; e < R->n_cigar[r0 + r]; e++) {
+                    const uint32_t ce = R->cigar[co + e];
+                    const uint32_t op = ce & 15u;
+                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += ce >> 4;
+                }
+                co += R->n_cigar[r0 + r];
+                span[r] = (int32_t)(ref_len - 1);
+            }
+            auto& g = c->contigs[R->cont_contig[k]];
+            int32_t at = -1;
+            int64_t pos_out = g.tracks_pos;
+            const int rc = tracks_windows_from(m, R->aln_start + r0, span.data(), R->rflags + r0, R->mapq + r0, pol, n_pol, g.len,
+                                               window, g.tracks_pos, h_wpos + r0, &at, &pos_out);
+            if (rc) {
+                j->early_rc = rc;  // reported by wait; nothing is launched for this job
+                break;
+            }
+            g.tracks_pos = pos_out;
+        }
+    }
+
+    // ---- device buffers ----
+    struct Dev {
+        uint8_t *bases, *quals, *rflags, *mapq, *scores, *force, *mask_ws, *mats, *codes25;
+        int32_t *read_len, *aln_start, *n_cigar, *read_cont, *first, *counts, *list, *wpos, *qstatus;
+        uint32_t* cigar;
+        int64_t *base_off, *cigar_off, *scan_ws, *total, *hist;
+        cramgpu_refwin* win;
+        cramgpu_policy* pol;
+        cramgpu_features F1, F2;
+    } D{};
+    auto carve_feats = [&](Carver& cv, cramgpu_features& F) {
+        F.op = cv.take<uint8_t>((size_t)cap + 16);
+        F.pos = cv.take<int32_t>((size_t)cap + 4);
+        F.a = cv.take<int32_t>((size_t)cap + 4);
+        F.b = cv.take<int32_t>((size_t)cap + 4);
+        F.off = cv.take<int64_t>((size_t)n + 1);
+        F.cap = cap;
+    };
+    auto layout = [&](Carver& cv) {
+        D.bases = cv.take<uint8_t>((size_t)nb + 32);
+        D.quals = lossy ? cv.take<uint8_t>((size_t)nb + 32) : nullptr;
+        D.read_len = cv.take<int32_t>((size_t)n + 4);
+        D.aln_start = cv.take<int32_t>((size_t)n + 4);
+        D.n_cigar = cv.take<int32_t>((size_t)n + 4);
+        D.rflags = cv.take<uint8_t>((size_t)n + 16);
+        D.mapq = cv.take<uint8_t>((size_t)n + 16);
+        D.cigar = cv.take<uint32_t>((size_t)ncg + 4);
+        D.base_off = cv.take<int64_t>((size_t)n + 1);
+        D.cigar_off = cv.take<int64_t>((size_t)n + 1);
+        D.read_cont = cv.take<int32_t>((size_t)n + 4);
+        D.first = cv.take<int32_t>((size_t)nc + 1);
+        D.win = cv.take<cramgpu_refwin>(nc);
+        D.counts = cv.take<int32_t>((size_t)n + 4);
+        D.list = cv.take<int32_t>((size_t)n + 4);
+        D.scan_ws = cv.take<int64_t>(feature_scan_ws_elems(n));
+        D.total = cv.take<int64_t>(4);
+        D.hist = cv.take<int64_t>((size_t)nc * 25);
+        D.mats = cv.take<uint8_t>((size_t)nc * 5 + 16);
+        D.codes25 = cv.take<uint8_t>((size_t)nc * 25 + 16);
+        carve_feats(cv, D.F1);
+        if (lossy) {
+            D.pol = cv.take<cramgpu_policy>(64);
+            D.wpos = cv.take<int32_t>((size_t)n + 4);
+            D.scores = cv.take<uint8_t>((size_t)nb + 32);
+            D.force = cv.take<uint8_t>((size_t)n + 16);
+            D.qstatus = cv.take<int32_t>((size_t)n + 4);
+            D.mask_ws = cv.take<uint8_t>(max_len + 1 > 16384 ? (size_t)nb + (size_t)n + 64 : 64);
+            carve_feats(cv, D.F2);
+        }
+    };
+    Carver measure{nullptr};
+    layout(measure);
+    if (!ok(j->arena.reserve(measure.off + 256))) return nullptr;
+    Carver cv{j->arena.p};
+    layout(cv);
+    j->feat_cap = cap;
+    j->h_feat_count = out->feats.off + n;
+
+    const bool run = j->early_rc == 0;
+    bool good = true;
+    auto up = [&](void* d, const void* h, size_t bytes) {
+        if (good && bytes) good = ok(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+    };
+    auto step = [&](hipError_t e) {
+        if (good) good = ok(e);
+    };
+    if (run) {
+        up(D.bases, R->bases, (size_t)nb);
+        if (lossy) up(D.quals, R->quals, (size_t)nb);
+        up(D.read_len, R->read_len, (size_t)n * 4);
+        up(D.aln_start, R->aln_start, (size_t)n * 4);
+        up(D.n_cigar, R->n_cigar, (size_t)n * 4);
+        up(D.rflags, R->rflags, (size_t)n);
+        if (R->mapq) up(D.mapq, R->mapq, (size_t)n);
+        up(D.cigar, R->cigar, (size_t)ncg * 4);
+        up(D.win, h_win, (size_t)nc * sizeof(cramgpu_refwin));
+        up(D.first, h_first, ((size_t)nc + 1) * 4);
+        step(hipMemsetAsync(D.hist, 0, (size_t)nc * 25 * sizeof(int64_t), s));
+        // offsets and container indices on the device (no 16 bytes per read across PCIe for what a scan gives)
+        step(launch_feature_scan(n, D.read_len, D.base_off, D.total, D.scan_ws, s));
+        step(launch_feature_scan(n, D.n_cigar, D.cigar_off, D.total, D.scan_ws, s));
+        step(launch_fill_read_cont(n, D.first, nc, D.read_cont, s));
+        cramgpu_reads dr{};
+        dr.n_reads = n, dr.n_cont = nc, dr.n_bases = nb, dr.max_read_len = max_len;
+        dr.bases = D.bases, dr.quals = D.quals, dr.base_off = D.base_off, dr.read_len = D.read_len;
+        dr.aln_start = D.aln_start, dr.rflags = D.rflags, dr.mapq = D.mapq, dr.cigar = D.cigar;
+        dr.cigar_off = D.cigar_off, dr.n_cigar = D.n_cigar, dr.read_cont = D.read_cont, dr.win = D.win;
+        const uint8_t* ref0 = nullptr;  // windows carry device addresses (build_windows)
+        uint32_t* list_n = reinterpret_cast<uint32_t*>(D.list + n);
+        // K3: count, scan, write (the write pass checks the capacity on the device: nothing here waits for the count)
+        if (n > 0) step(launch_extract_features(dr, ref0, D.F1, nullptr, D.counts, false, D.list, list_n, nullptr, s));
+        step(launch_feature_scan(n, D.counts, D.F1.off, D.total, D.scan_ws, s));
+        if (n > 0) step(launch_extract_features(dr, ref0, D.F1, D.hist, D.counts, true, D.list, list_n, D.total, s));
+        // F3 + codes
+        step(launch_matrices_and_codes(D.hist, nc, D.mats, D.codes25, n, D.read_cont, D.F1.off, D.F1.op, D.F1.a, s));
+        const cramgpu_features* Fout = &D.F1;
+        if (lossy) {
+            up(D.pol, h_pol, sizeof(pol));
+            up(D.wpos, h_wpos, (size_t)n * 4);
+            if (n > 0) {
+                step(launch_lossy_quals(dr, ref0, D.wpos, window, D.pol, n_pol, D.scores, D.force, D.qstatus, D.mask_ws, s));
+                step(launch_merge_quality(n, D.read_len, D.base_off, D.scores, D.force, D.qstatus, D.F1, D.F2, D.counts, false,
+                                          nullptr, s));
+            }
+            step(launch_feature_scan(n, D.counts, D.F2.off, D.total + 1, D.scan_ws, s));
+            // the merged set only exists if the first one fitted; its own count decides its write pass
+            if (n > 0)
+                step(launch_merge_quality(n, D.read_len, D.base_off, D.scores, D.force, D.qstatus, D.F1, D.F2, D.counts, true,
+                                          D.total + 1, s));
+            Fout = &D.F2;
+        }
+        // phase 1 of the way back: offsets and the count
+        const int64_t* d_count = lossy ? D.total + 1 : D.total;
+        if (good) good = ok(hipMemcpyAsync(out->feats.off, Fout->off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (good) good = ok(hipMemcpyAsync(j->h_total, d_count, 8, hipMemcpyDeviceToHost, s));
+        j->back.push_back({out->feats.op, Fout->op, 1, true});
+        j->back.push_back({out->feats.pos, Fout->pos, 4, true});
+        j->back.push_back({out->feats.a, Fout->a, 4, true});
+        j->back.push_back({out->feats.b, Fout->b, 4, true});
+        j->back.push_back({out->matrices, D.mats, (size_t)nc * 5, false});
+        if (out->sub_hist) j->back.push_back({out->sub_hist, D.hist, (size_t)nc * 25 * 8, false});
+        if (lossy) {
+            j->back.push_back({out->scores, D.scores, (size_t)nb, false});
+            j->back.push_back({out->force, D.force, (size_t)n, false});
+            j->back.push_back({out->status, D.qstatus, (size_t)n * 4, false});
+        }
+    } else {
+        j->h_feat_count = nullptr;
+    }
+    if (!good || !ok(hipEventRecord(j->coded, s))) return nullptr;
+    j->busy = true;
+    return j;
+}
+
+cramgpu_job* cramgpu_submit_restore(cramgpu_ctx* c, const cramgpu_host_records* R, cramgpu_host_restore_results* out) {
+    if (!c || !R || !out || R->n_reads < 0 || R->n_cont < 1 || R->n_seq < 0 || !R->cont_reads || !R->cont_contig ||
+        !R->matrices || !R->feats.off || !out->bases || !out->status_bases ||
+        (R->n_reads > 0 && (!R->read_len || !R->aln_start || !R->rflags)) || (out->scores && !out->status_quals)) {
+        fail(CRAMGPU_E_ARG, "cramgpu_submit_restore: bad argument");
+        return nullptr;
+    }
+    const int32_t n = R->n_reads, nc = R->n_cont;
+    const int64_t nf = R->feats.off[n];
+    if (nf < 0 || (nf > 0 && (!R->feats.op || !R->feats.pos || !R->feats.a || !R->feats.b))) {
+        fail(CRAMGPU_E_ARG, "cramgpu_submit_restore: feature arrays missing");
+        return nullptr;
+    }
+    std::vector<int32_t> cont_first((size_t)nc + 1, 0);
+    for (int32_t k = 0; k < nc; k++) cont_first[k + 1] = cont_first[k] + std::max(0, R->cont_reads[k]);
+    int64_t nb = 0;
+    for (int32_t r = 0; r < n; r++) {
+        if (R->read_len[r] < 0) {
+            fail(CRAMGPU_E_ARG, "cramgpu_submit_restore: negative read length");
+            return nullptr;
+        }
+        nb += R->read_len[r];
+    }
+    if (cont_first[nc] != n) {
+        fail(CRAMGPU_E_ARG, "cramgpu_submit_restore: cont_reads does not add up to n_reads");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    cramgpu_job* j = grab_job(c, 2);
+    if (!j) return nullptr;
+    hipStream_t s = j->stream;
+    auto ok = [&](hipError_t e) { return e == hipSuccess || (fail(CRAMGPU_E_HIP, hipGetErrorString(e)), false); };
+    const size_t pin_bytes = 256 + (size_t)nc * sizeof(cramgpu_refwin) + 256 + ((size_t)nc + 1) * 4 + 256 + (size_t)nc * 20 + 256;
+    if (!ok(j->pin.reserve(pin_bytes))) return nullptr;
+    Carver hp{j->pin.p};
+    j->h_total = hp.take<int64_t>(2);
+    j->h_total[0] = 0;
+    cramgpu_refwin* h_win = hp.take<cramgpu_refwin>(nc);
+    int32_t* h_first = hp.take<int32_t>((size_t)nc + 1);
+    uint8_t* h_basesof = hp.take<uint8_t>((size_t)nc * 20);
+    if (build_windows(c, nc, R->cont_contig, R->cont_win_start0, R->cont_win_len, h_win)) return nullptr;
+    memcpy(h_first, cont_first.data(), ((size_t)nc + 1) * 4);
+    {
+        uint8_t tmp[5 * 256];
+        for (int32_t k = 0; k < nc; k++) matrix_tables(R->matrices + 5 * k, tmp, h_basesof + (size_t)k * 20);
+    }
+    struct Dev {
+        uint8_t *rflags, *seq, *basesof, *bases, *scores;
+        int32_t *read_len, *aln_start, *read_cont, *first, *st_b, *st_q;
+        int64_t *out_off, *seq_off, *scan_ws, *total;
+        cramgpu_refwin* win;
+        cramgpu_features F;
+    } D{};
+    auto layout = [&](Carver& cv) {
+        D.read_len = cv.take<int32_t>((size_t)n + 4);
+        D.aln_start = cv.take<int32_t>((size_t)n + 4);
+        D.rflags = cv.take<uint8_t>((size_t)n + 16);
+        D.read_cont = cv.take<int32_t>((size_t)n + 4);
+        D.first = cv.take<int32_t>((size_t)nc + 1);
+        D.win = cv.take<cramgpu_refwin>(nc);
+        D.basesof = cv.take<uint8_t>((size_t)nc * 20 + 16);
+        D.out_off = cv.take<int64_t>((size_t)n + 1);
+        D.seq_off = cv.take<int64_t>((size_t)n + 1);
+        D.scan_ws = cv.take<int64_t>(feature_scan_ws_elems(n));
+        D.total = cv.take<int64_t>(4);
+        D.seq = cv.take<uint8_t>((size_t)R->n_seq + 32);
+        D.bases = cv.take<uint8_t>((size_t)nb + 32);
+        D.scores = cv.take<uint8_t>((size_t)nb + 32);
+        D.st_b = cv.take<int32_t>((size_t)n + 4);
+        D.st_q = cv.take<int32_t>((size_t)n + 4);
+        D.F.op = cv.take<uint8_t>((size_t)nf + 16);
+        D.F.pos = cv.take<int32_t>((size_t)nf + 4);
+        D.F.a = cv.take<int32_t>((size_t)nf + 4);
+        D.F.b = cv.take<int32_t>((size_t)nf + 4);
+        D.F.off = cv.take<int64_t>((size_t)n + 1);
+        D.F.cap = nf;
+    };
+    Carver measure{nullptr};
+    layout(measure);
+    if (!ok(j->arena.reserve(measure.off + 256))) return nullptr;
+    Carver cv{j->arena.p};
+    layout(cv);
+    bool good = true;
+    auto up = [&](void* d, const void* h, size_t bytes) {
+        if (good && bytes) good = ok(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+    };
+    auto step = [&](hipError_t e) {
+        if (good) good = ok(e);
+    };
+    up(D.read_len, R->read_len, (size_t)n * 4);
+    up(D.aln_start, R->aln_start, (size_t)n * 4);
+    up(D.rflags, R->rflags, (size_t)n);
+    up(D.first, h_first, ((size_t)nc + 1) * 4);
+    up(D.win, h_win, (size_t)nc * sizeof(cramgpu_refwin));
+    up(D.basesof, h_basesof, (size_t)nc * 20);
+    up(D.F.op, R->feats.op, (size_t)nf);
+    up(D.F.pos, R->feats.pos, (size_t)nf * 4);
+    up(D.F.a, R->feats.a, (size_t)nf * 4);
+    up(D.F.b, R->feats.b, (size_t)nf * 4);
+    up(D.F.off, R->feats.off, ((size_t)n + 1) * 8);
+    if (R->seq && R->n_seq) up(D.seq, R->seq, (size_t)R->n_seq);
+    if (R->seq_off)
+        up(D.seq_off, R->seq_off, (size_t)n * 8);
+    else
+        step(hipMemsetAsync(D.seq_off, 0, ((size_t)n + 1) * 8, s));
+    if (out->scores) up(D.scores, out->scores, (size_t)nb);
+    step(launch_feature_scan(n, D.read_len, D.out_off, D.total, D.scan_ws, s));
+    step(launch_fill_read_cont(n, D.first, nc, D.read_cont, s));
+    if (n > 0) {
+        step(launch_restore_bases(n, D.read_len, D.aln_start, D.rflags, D.read_cont, D.win, D.F, D.seq, D.seq_off, R->n_seq, nullptr,
+                                  D.basesof, D.bases, D.out_off, D.st_b, s));
+        if (out->scores)
+            step(launch_restore_quals(n, D.read_len, D.rflags, D.F, (uint8_t)R->default_qs, D.scores, D.out_off, D.st_q, s));
+    }
+    j->feat_cap = 0;
+    j->back.push_back({out->bases, D.bases, (size_t)nb, false});
+    j->back.push_back({out->status_bases, D.st_b, (size_t)n * 4, false});
+    if (out->scores) {
+        j->back.push_back({out->scores, D.scores, (size_t)nb, false});
+        j->back.push_back({out->status_quals, D.st_q, (size_t)n * 4, false});
+    }
+    if (!good || !ok(hipEventRecord(j->coded, s))) return nullptr;
+    j->busy = true;
+    return j;
 }
 
 }  // extern "C"

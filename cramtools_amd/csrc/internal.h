@@ -59,7 +59,10 @@ hipError_t launch_gather(const uint8_t* src, const int64_t* pos, const int32_t* 
 // record kernels
 void records_set_cu_count(int n_cu);  // grid sizing of the record kernels
 hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
-                                   int32_t* d_counts, bool write_pass, int32_t* list, uint32_t* list_n, hipStream_t s);
+                                   int32_t* d_counts, bool write_pass, int32_t* list, uint32_t* list_n,
+                                   const int64_t* d_total_guard, hipStream_t s);  // guard: write nothing if *guard > f.cap
+hipError_t launch_fill_read_cont(int32_t n_reads, const int32_t* d_cont_first, int32_t n_cont, int32_t* d_read_cont,
+                                 hipStream_t s);
 size_t feature_scan_ws_elems(int32_t n_reads);  // int64 elements of workspace launch_feature_scan needs
 hipError_t launch_feature_scan(int32_t n_reads, const int32_t* d_counts, int64_t* d_off, int64_t* d_total, int64_t* d_ws,
                                hipStream_t s);
@@ -79,4 +82,4 @@ hipError_t launch_lossy_quals(const cramgpu_reads& r, const uint8_t* ref, const 
                               int32_t* status, uint8_t* d_mask_ws, hipStream_t s);
 hipError_t launch_merge_quality(int32_t n_reads, const int32_t* read_len, const int64_t* base_off, const uint8_t* scores,
                                 const uint8_t* force, const int32_t* qstatus, cramgpu_features in, cramgpu_features out,
-                                int32_t* d_counts, bool write_pass, hipStream_t s);
+                                int32_t* d_counts, bool write_pass, const int64_t* d_total_guard, hipStream_t s);

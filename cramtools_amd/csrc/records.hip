@@ -63,7 +63,10 @@ __device__ __forceinline__ int64_t lane_bcast(int64_t v, int k) {
 
 template <bool WRITE>
 __global__ __launch_bounds__(256) void extract_kernel(cramgpu_reads R, const uint8_t* ref, cramgpu_features F,
-                                                      int64_t* sub_hist, int32_t* counts, int tile_reads) {
+                                                      int64_t* sub_hist, int32_t* counts, int tile_reads,
+                                                      const int64_t* total) {
+    // write pass of a stream-ordered caller: the host has not seen the count, so the capacity check happens here
+    if (WRITE && total && *total > F.cap) return;
     // tile_reads = 64: the tiled walk described above; tile_reads = 1: a wave per read (long reads: a tile of 64
     // ten-kilobase reads would keep one wave busy for 640 000 bases while most of the GPU idles)
     const int lane = threadIdx.x & 63;
@@ -379,7 +382,8 @@ __global__ __launch_bounds__(256) void extract_lane_count_kernel(cramgpu_reads R
 
 __global__ __launch_bounds__(256) void extract_lane_write_kernel(cramgpu_reads R, const uint8_t* ref, cramgpu_features F,
                                                                  int64_t* sub_hist, const int32_t* list,
-                                                                 const uint32_t* list_n) {
+                                                                 const uint32_t* list_n, const int64_t* total) {
+    if (total && *total > F.cap) return;  // see extract_kernel
     const uint32_t n = *list_n;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -1124,9 +1128,10 @@ __global__ __launch_bounds__(64) void lossy_quals_kernel(cramgpu_reads R, const 
 template <bool WRITE>
 __global__ void merge_quality_kernel(int32_t n_reads, const int32_t* read_len, const int64_t* base_off,
                                      const uint8_t* scores, const uint8_t* force, const int32_t* qstatus,
-                                     cramgpu_features in, cramgpu_features out, int32_t* counts) {
+                                     cramgpu_features in, cramgpu_features out, int32_t* counts, const int64_t* total) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
+    if (WRITE && total && *total > out.cap) return;  // see extract_kernel
     int64_t f = in.off[r];
     const int64_t fe = in.off[r + 1];
     const bool addq = qstatus[r] == 0 && !force[r];
@@ -1189,12 +1194,13 @@ static int grid_for_waves(int64_t n_items, int waves_per_block) {
 }
 
 hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
-                                   int32_t* d_counts, bool write_pass, int32_t* list, uint32_t* list_n, hipStream_t s) {
+                                   int32_t* d_counts, bool write_pass, int32_t* list, uint32_t* list_n,
+                                   const int64_t* d_total_guard, hipStream_t s) {
     if (r.max_read_len <= kLaneReadMax && list && list_n) {  // short reads: a lane per read
         if (write_pass) {
             // the list holds the reads with features: at most n_reads, usually a small fraction
             hipLaunchKernelGGL(extract_lane_write_kernel, dim3(lane_grid(((int64_t)r.n_reads + 3) / 4)), dim3(256), 0, s, r,
-                               ref, f, sub_hist, list, list_n);
+                               ref, f, sub_hist, list, list_n, d_total_guard);
         } else {
             hipError_t e = hipMemsetAsync(list_n, 0, sizeof(uint32_t), s);
             if (e != hipSuccess) return e;
@@ -1206,9 +1212,36 @@ hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, c
     const int tile_reads = r.max_read_len > kLaneReadMax ? 1 : 64;  // long reads: a wave each
     const int grid = grid_for_waves(((int64_t)r.n_reads + tile_reads - 1) / tile_reads, 4);
     if (write_pass)
-        hipLaunchKernelGGL(extract_kernel<true>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts, tile_reads);
+        hipLaunchKernelGGL(extract_kernel<true>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts, tile_reads,
+                           d_total_guard);
     else
-        hipLaunchKernelGGL(extract_kernel<false>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts, tile_reads);
+        hipLaunchKernelGGL(extract_kernel<false>, dim3(grid), dim3(256), 0, s, r, ref, f, sub_hist, d_counts, tile_reads,
+                           d_total_guard);
+    return hipGetLastError();
+}
+
+namespace {
+// read_cont[r] = container of read r from the containers' first-read table cont_first[n_cont + 1] (binary search)
+__global__ void fill_read_cont_kernel(int32_t n_reads, const int32_t* cont_first, int32_t n_cont, int32_t* read_cont) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int lo = 0, hi = n_cont - 1;  // largest c with cont_first[c] <= r
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (cont_first[mid] <= r)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    read_cont[r] = lo;
+}
+}  // namespace
+
+hipError_t launch_fill_read_cont(int32_t n_reads, const int32_t* d_cont_first, int32_t n_cont, int32_t* d_read_cont,
+                                 hipStream_t s) {
+    if (n_reads > 0)
+        hipLaunchKernelGGL(fill_read_cont_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, s, n_reads, d_cont_first, n_cont,
+                           d_read_cont);
     return hipGetLastError();
 }
 
@@ -1276,13 +1309,13 @@ hipError_t launch_lossy_quals(const cramgpu_reads& r, const uint8_t* ref, const 
 
 hipError_t launch_merge_quality(int32_t n_reads, const int32_t* read_len, const int64_t* base_off, const uint8_t* scores,
                                 const uint8_t* force, const int32_t* qstatus, cramgpu_features in, cramgpu_features out,
-                                int32_t* d_counts, bool write_pass, hipStream_t s) {
+                                int32_t* d_counts, bool write_pass, const int64_t* d_total_guard, hipStream_t s) {
     const int grid = (n_reads + 255) / 256;
     if (write_pass)
         hipLaunchKernelGGL(merge_quality_kernel<true>, dim3(grid), dim3(256), 0, s, n_reads, read_len, base_off, scores,
-                           force, qstatus, in, out, d_counts);
+                           force, qstatus, in, out, d_counts, d_total_guard);
     else
         hipLaunchKernelGGL(merge_quality_kernel<false>, dim3(grid), dim3(256), 0, s, n_reads, read_len, base_off, scores,
-                           force, qstatus, in, out, d_counts);
+                           force, qstatus, in, out, d_counts, d_total_guard);
     return hipGetLastError();
 }

@@ -312,3 +312,129 @@ class QualityScorePreservation:
         out.count = int(n)
         torch.cuda.synchronize()
         return out
+
+
+# ======================================================================================================
+# Host form of level 2 (cramgpu_submit_reads / cramgpu_submit_restore): numpy arrays in, numpy arrays out, no torch.
+# This is the call sequence of the JNI shim of INTEGRATION.md, written in Python because the image has no JVM.
+# ======================================================================================================
+def _np(x, dtype):
+    return np.ascontiguousarray(x, dtype)
+
+
+def ref_upload(engine, contig, bases):
+    """ReferenceSource.getReferenceBases -> Sam2CramRecordFactory#setRefBases: one contig's bases to the GPU, once."""
+    b = _np(np.frombuffer(bytes(bases), np.uint8) if isinstance(bases, (bytes, bytearray)) else bases, np.uint8)
+    _lib.check(_lib.lib().cramgpu_ref_upload(engine.handle, int(contig), b.ctypes.data, b.size))
+
+
+class HostReadJob:
+    """One outstanding cramgpu_submit_reads: keeps the host arrays alive until wait()."""
+
+    def __init__(self, engine, starts, cigars, bases, cont_reads, cont_contig, quals=None, mapq=None, rflags=None,
+                 lossy_spec=None, window=0, feat_cap=None):
+        n = len(starts)
+        packed = [pack_cigar(c) if isinstance(c, str) else list(c) for c in cigars]
+        self.read_len = _np([len(b) for b in bases], np.int32)
+        self.bases = _np(np.frombuffer(b"".join(bytes(b) for b in bases) + b"\0" * 16, np.uint8), np.uint8)
+        self.quals = (_np(np.frombuffer(b"".join(bytes(q) for q in quals) + b"\0" * 16, np.uint8), np.uint8)
+                      if quals is not None else None)
+        self.aln_start = _np(starts, np.int32)
+        self.rflags = _np(rflags if rflags is not None else np.zeros(n), np.uint8)
+        self.mapq = _np(mapq if mapq is not None else np.full(n, 60), np.uint8)
+        self.n_cigar = _np([len(c) for c in packed], np.int32)
+        self.cigar = _np([x for c in packed for x in c] + [0], np.uint32)
+        self.cont_reads = _np(cont_reads, np.int32)
+        self.cont_contig = _np(cont_contig, np.int32)
+        nb, nc = int(self.read_len.sum()), self.cont_reads.size
+        cap = int(feat_cap if feat_cap is not None else n * 8 + 1024)
+        self.n, self.nb, self.nc, self.cap, self.lossy = n, nb, nc, cap, lossy_spec is not None
+        self.f_op, self.f_pos = np.zeros(cap + 1, np.uint8), np.zeros(cap + 1, np.int32)
+        self.f_a, self.f_b = np.zeros(cap + 1, np.int32), np.zeros(cap + 1, np.int32)
+        self.f_off = np.zeros(n + 1, np.int64)
+        self.matrices, self.hist = np.zeros(nc * 5, np.uint8), np.zeros(nc * 25, np.int64)
+        self.scores, self.force = np.zeros(nb + 1, np.uint8), np.zeros(n + 1, np.uint8)
+        self.status = np.zeros(n + 1, np.int32)
+        hr = _lib.HostReads()
+        hr.n_reads, hr.n_cont, hr.n_bases, hr.n_cigar_ops = n, nc, nb, int(self.n_cigar.sum())
+        hr.bases, hr.quals = self.bases.ctypes.data, self.quals.ctypes.data if self.quals is not None else None
+        hr.read_len, hr.aln_start = self.read_len.ctypes.data, self.aln_start.ctypes.data
+        hr.rflags, hr.mapq = self.rflags.ctypes.data, self.mapq.ctypes.data
+        hr.cigar, hr.n_cigar = self.cigar.ctypes.data, self.n_cigar.ctypes.data
+        hr.cont_reads, hr.cont_contig = self.cont_reads.ctypes.data, self.cont_contig.ctypes.data
+        out = _lib.HostReadResults()
+        out.feats.op, out.feats.pos = self.f_op.ctypes.data, self.f_pos.ctypes.data
+        out.feats.a, out.feats.b = self.f_a.ctypes.data, self.f_b.ctypes.data
+        out.feats.off, out.feats.cap = self.f_off.ctypes.data, cap
+        out.matrices, out.sub_hist = self.matrices.ctypes.data, self.hist.ctypes.data
+        if self.lossy:
+            out.scores, out.force, out.status = self.scores.ctypes.data, self.force.ctypes.data, self.status.ctypes.data
+        self._hr, self._out = hr, out
+        self.job = _lib.lib().cramgpu_submit_reads(engine.handle, C.byref(hr), lossy_spec.encode() if self.lossy else None,
+                                                   int(window), C.byref(out))
+        if not self.job:
+            raise CramGpuError(_lib.E_ARG, _lib.last_error())
+
+    def done(self):
+        return _lib.check(_lib.lib().cramgpu_job_poll(self.job)) == 1
+
+    def wait(self):
+        """-> dict(op, pos, a, b, off, matrices[n_cont,5], hist[n_cont,25][, scores, force, status])."""
+        rc = _lib.lib().cramgpu_job_wait(self.job)
+        if rc == _lib.E_INSUFFICIENT:
+            raise CramGpuError(rc, "feature capacity %d, needed %d" % (self.cap, int(self.f_off[self.n])))
+        _lib.check(rc)
+        k = int(self.f_off[self.n])
+        res = dict(op=self.f_op[:k], pos=self.f_pos[:k], a=self.f_a[:k], b=self.f_b[:k], off=self.f_off,
+                   matrices=self.matrices.reshape(self.nc, 5), hist=self.hist.reshape(self.nc, 25))
+        if self.lossy:
+            res.update(scores=self.scores[:self.nb], force=self.force[:self.n], status=self.status[:self.n])
+        return res
+
+
+class HostRestoreJob:
+    """One outstanding cramgpu_submit_restore (CramNormalizer.restoreReadBases + restoreQualityScores)."""
+
+    def __init__(self, engine, read_len, aln_start, rflags, cont_reads, cont_contig, feats, matrices, seq=None, seq_off=None,
+                 scores=None, windows=None, default_qs=DEFAULT_QUALITY_SCORE):
+        n = len(read_len)
+        self.read_len, self.aln_start = _np(read_len, np.int32), _np(aln_start, np.int32)
+        self.rflags = _np(rflags, np.uint8)
+        self.cont_reads, self.cont_contig = _np(cont_reads, np.int32), _np(cont_contig, np.int32)
+        self.f = [_np(feats["op"], np.uint8), _np(feats["pos"], np.int32), _np(feats["a"], np.int32),
+                  _np(feats["b"], np.int32), _np(feats["off"], np.int64)]
+        self.matrices = _np(matrices, np.uint8).reshape(-1)
+        self.seq = _np(seq, np.uint8) if seq is not None else np.zeros(16, np.uint8)
+        self.seq_off = _np(seq_off, np.int64) if seq_off is not None else None
+        nb = int(self.read_len.sum())
+        self.n, self.nb = n, nb
+        self.bases = np.zeros(nb + 1, np.uint8)
+        self.scores = _np(scores, np.uint8).copy() if scores is not None else None
+        self.st_b, self.st_q = np.zeros(n + 1, np.int32), np.zeros(n + 1, np.int32)
+        hr = _lib.HostRecords()
+        hr.n_reads, hr.n_cont, hr.n_seq = n, self.cont_reads.size, self.seq.size if seq is not None else 0
+        hr.read_len, hr.aln_start, hr.rflags = self.read_len.ctypes.data, self.aln_start.ctypes.data, self.rflags.ctypes.data
+        hr.cont_reads, hr.cont_contig = self.cont_reads.ctypes.data, self.cont_contig.ctypes.data
+        if windows is not None:
+            w = _np(windows, np.int64).reshape(-1, 2)
+            self.w0, self.wl = _np(w[:, 0], np.int64), _np(w[:, 1], np.int64)
+            hr.cont_win_start0, hr.cont_win_len = self.w0.ctypes.data, self.wl.ctypes.data
+        hr.feats.op, hr.feats.pos, hr.feats.a, hr.feats.b, hr.feats.off = [x.ctypes.data for x in self.f]
+        hr.feats.cap = self.f[0].size
+        hr.seq, hr.seq_off = self.seq.ctypes.data, self.seq_off.ctypes.data if self.seq_off is not None else None
+        hr.matrices, hr.default_qs = self.matrices.ctypes.data, int(default_qs)
+        out = _lib.HostRestoreResults()
+        out.bases, out.status_bases = self.bases.ctypes.data, self.st_b.ctypes.data
+        if self.scores is not None:
+            out.scores, out.status_quals = self.scores.ctypes.data, self.st_q.ctypes.data
+        self._hr, self._out = hr, out
+        self.job = _lib.lib().cramgpu_submit_restore(engine.handle, C.byref(hr), C.byref(out))
+        if not self.job:
+            raise CramGpuError(_lib.E_ARG, _lib.last_error())
+
+    def wait(self):
+        """-> (bases, status_bases, scores or None, status_quals or None)."""
+        _lib.check(_lib.lib().cramgpu_job_wait(self.job))
+        if self.scores is None:
+            return self.bases[:self.nb], self.st_b[:self.n], None, None
+        return self.bases[:self.nb], self.st_b[:self.n], self.scores[:self.nb], self.st_q[:self.n]

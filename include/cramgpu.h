@@ -148,6 +148,7 @@ int32_t cramgpu_rans_decode_batch(cramgpu_ctx* ctx, const uint8_t* in_arena, int
  * fetches lengths with hipMemcpyAsync on the job slot's own stream and returns at once; the Java thread marshals the
  * next container meanwhile.  cramgpu_job_wait brings the streams into out_arena (as cramgpu_rans_*_batch leaves
  * them) and out_len, and releases the job; cramgpu_job_poll says whether wait would block (1 = finished).
+ * (cramgpu_job_poll / cramgpu_job_wait also serve the jobs of cramgpu_submit_reads / cramgpu_submit_restore.)
  * Arenas and out_len must stay valid and untouched from submit to wait; for copies that overlap host work they
  * should come from cramgpu_host_alloc (pinned memory, exposed to Java as direct ByteBuffers).  At most
  * CRAMGPU_MAX_JOBS may be outstanding per context (submit fails with CRAMGPU_E_ARG beyond); every slot has its own
@@ -312,6 +313,93 @@ int64_t cramgpu_merge_quality_features_dev(cramgpu_ctx* ctx, int32_t n_reads, co
                                            const int64_t* d_base_off, const uint8_t* d_scores, const uint8_t* d_force,
                                            const int32_t* d_qstatus, const cramgpu_features* in, cramgpu_features* out,
                                            void* stream);
+
+/* =====================================================================================================
+ * Level 2, host form — what a JNI shim calls: no HIP on the caller's side, asynchronous like cramgpu_rans_submit.
+ * The stripe shape is the one src/main/java/htsjdk/samtools/cram/paralell/Bam_OBA_Supplier.java:45-82 cuts (at most
+ * 10 000 records of one reference per container), marshalled to structure-of-arrays form by the shim inside
+ * Sam2CramRecordFactory.createCramRecord / CramNormalizer.normalize (CramNormalizer.java:66,145) /
+ * QualityScorePreservation.addQualityScores (QualityScorePreservation.java:276).  All arrays are HOST memory (best
+ * from cramgpu_host_alloc, so that the copies overlap) and must stay valid and untouched from submit to
+ * cramgpu_job_wait; jobs share the CRAMGPU_MAX_JOBS slots of the context with cramgpu_rans_submit.
+ * ===================================================================================================== */
+#define CRAMGPU_MAX_CONTIGS 4096
+
+/* Reference bases of one contig (upper-cased by the host as ReferenceSource does, ReferenceSource.java:239), copied to
+ * the device once and kept by the context: Sam2CramRecordFactory#setRefBases (CramSerilization.java:147-151) on
+ * encode, ReferenceSource.getRegion (CramNormalizer.java:212-226) on decode.  Synchronous; replaces an earlier upload
+ * of the same id and resets the contig's ReferenceTracks window to position 1. */
+int32_t cramgpu_ref_upload(cramgpu_ctx* ctx, int32_t contig, const uint8_t* bases, int64_t len);
+int32_t cramgpu_ref_drop(cramgpu_ctx* ctx, int32_t contig);
+
+/* Reads of n_cont containers (encode side): the fields of cramgpu_reads a host has at hand; offsets, container
+ * indices and reference windows are derived by the library. */
+typedef struct {
+    int32_t n_reads;
+    int32_t n_cont;
+    int64_t n_bases;             /* sum of read_len */
+    int64_t n_cigar_ops;         /* sum of n_cigar */
+    const uint8_t* bases;        /* [n_bases] read after read */
+    const uint8_t* quals;        /* [n_bases] or NULL (lossless callers keep their qualities) */
+    const int32_t* read_len;     /* [n_reads] */
+    const int32_t* aln_start;    /* [n_reads] 1-based, 0 = unplaced */
+    const uint8_t* rflags;       /* [n_reads] CRAMGPU_RF_* */
+    const uint8_t* mapq;         /* [n_reads] or NULL (lossy model only) */
+    const uint32_t* cigar;       /* [n_cigar_ops] BAM-packed */
+    const int32_t* n_cigar;      /* [n_reads] */
+    const int32_t* cont_reads;   /* [n_cont] reads per container, in order */
+    const int32_t* cont_contig;  /* [n_cont] contig id (cramgpu_ref_upload) of each container */
+} cramgpu_host_reads;
+
+/* Where cramgpu_submit_reads leaves its results (host memory of the caller). */
+typedef struct {
+    cramgpu_features feats;      /* HOST arrays; after the wait feats.off[n_reads] = number of features */
+    uint8_t* matrices;           /* [n_cont * 5] SubstitutionMatrix header bytes */
+    int64_t* sub_hist;           /* [n_cont * 25] or NULL */
+    uint8_t* scores;             /* lossy: [n_bases], 0xFF = hole (r.qualityScores); NULL for lossless */
+    uint8_t* force;              /* lossy: [n_reads] setForcePreserveQualityScores */
+    int32_t* status;             /* lossy: [n_reads] as cramgpu_lossy_quals_dev */
+} cramgpu_host_read_results;
+
+/* createCramRecord for every read of the stripe: K3 feature extraction, F3 matrices and substitution codes and, when
+ * lossy_spec is not NULL, the lossy quality model (parsePolicies, the ReferenceTracks window replayed per contig
+ * across submissions in submission order, addQualityScores, the merged and position-sorted BaseQualityScore
+ * features).  window = ReferenceTracks window (0 = the reference's 1 000 000).  Returns a job or NULL
+ * (cramgpu_last_error).  cramgpu_job_wait returns CRAMGPU_E_INSUFFICIENT when out->feats.cap is too small
+ * (out->feats.off is complete then: off[n_reads] = capacity needed), CRAMGPU_E_JAVA_THROWS when ReferenceTracks would
+ * throw (reads of a container not sorted by start), CRAMGPU_E_UNSUPPORTED as cramgpu_lossy_quals_dev. */
+cramgpu_job* cramgpu_submit_reads(cramgpu_ctx* ctx, const cramgpu_host_reads* reads, const char* lossy_spec,
+                                  int32_t window, cramgpu_host_read_results* out);
+
+/* Records of n_cont containers on the decode side (what ContainerParser.getRecords leaves, flattened). */
+typedef struct {
+    int32_t n_reads;
+    int32_t n_cont;
+    int64_t n_seq;                   /* bytes in seq */
+    const int32_t* read_len;         /* [n_reads] */
+    const int32_t* aln_start;        /* [n_reads] */
+    const uint8_t* rflags;           /* [n_reads] CRAMGPU_RF_UNKNOWN_BASES / FORCE_QS / SKIP */
+    const int32_t* cont_reads;       /* [n_cont] */
+    const int32_t* cont_contig;      /* [n_cont] */
+    const int64_t* cont_win_start0;  /* [n_cont] 0-based start of the ReferenceRegion, or NULL = whole contigs */
+    const int64_t* cont_win_len;     /* [n_cont] its length (clipped to the contig) */
+    cramgpu_features feats;          /* HOST arrays, feats.off[n_reads] = number of features */
+    const uint8_t* seq;              /* bytes of S / I features */
+    const int64_t* seq_off;          /* [n_reads] */
+    const uint8_t* matrices;         /* [n_cont * 5] */
+    int32_t default_qs;              /* CramNormalizer.java:141,204: 30 */
+    int32_t reserved;
+} cramgpu_host_records;
+
+typedef struct {
+    uint8_t* bases;         /* [sum read_len] restored bases, read after read */
+    uint8_t* scores;        /* in/out [sum read_len] (0xFF = missing score) or NULL to skip restoreQualityScores */
+    int32_t* status_bases;  /* [n_reads] as cramgpu_restore_bases_dev */
+    int32_t* status_quals;  /* [n_reads] as cramgpu_restore_quals_dev (untouched when scores is NULL) */
+} cramgpu_host_restore_results;
+
+/* CramNormalizer.restoreReadBases (:335-441) and restoreQualityScores (:287-333) for every record of the stripe. */
+cramgpu_job* cramgpu_submit_restore(cramgpu_ctx* ctx, const cramgpu_host_records* recs, cramgpu_host_restore_results* out);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,10 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.Policy) == 80
     assert ctypes.sizeof(_lib.Features) == 48
     assert ctypes.sizeof(_lib.Reads) == 24 + 12 * 8
+    assert ctypes.sizeof(_lib.HostReads) == 24 + 10 * 8
+    assert ctypes.sizeof(_lib.HostReadResults) == 48 + 5 * 8
+    assert ctypes.sizeof(_lib.HostRecords) == 16 + 7 * 8 + 48 + 3 * 8 + 8
+    assert ctypes.sizeof(_lib.HostRestoreResults) == 32
 
 
 def test_host_only_entry_points():

@@ -97,6 +97,13 @@ def test_records_gpu_test_bodies(hostsim, katrec, orc, monkeypatch):
         eng.close()
 
 
+def test_host_stripe_test_bodies(hostsim, orc):
+    """cramgpu_ref_upload / cramgpu_submit_reads / cramgpu_submit_restore through host arrays (tests/test_host_stripes_gpu.py)."""
+    import test_host_stripes_gpu as t
+    t.test_host_stripes_encode_and_restore(orc)
+    t.test_host_stripes_lossy(orc)
+
+
 @SLOW
 def test_records_gpu_random_bodies(hostsim, orc, monkeypatch):
     import test_records_gpu as t
