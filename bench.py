@@ -348,6 +348,67 @@ def cpu_baseline(w, budget_s=15.0):
                        "(%d blocks, %.1f MB raw), one container per thread at a time" % (n_c, l.size, mb)), (out, ooff, olen, n_c)
 
 
+def pcie_inclusive(eng, w, per_job=256, n_cont=None, outstanding=4, reps=2, packed=True):
+    """PCIe-inclusive rate of the asynchronous host-arena boundary (cramgpu_rans_submit / cramgpu_job_wait, what a JNI
+    host uses): the containers' raw blocks start in pinned HOST arenas and the streams end there; `per_job` containers
+    per submission, `outstanding` jobs in flight; packed = cramgpu_rans_submit_packed (streams stay packed in the host
+    arena, the form a JNI host wants) instead of cramgpu_rans_submit (streams spread to their slots by a host memmove).
+    Never the headline `value` (inputs resident in HBM)."""
+    L = _lib.lib()
+    ns = len(SERIES)
+    n_cont = min(n_cont or w["n_cont"], w["n_cont"])
+    d_in = w["d_in"]
+    jobs = []
+    for j0 in range(0, n_cont, per_job):
+        idx = range(j0 * ns, min(j0 + per_job, n_cont) * ns)
+        lens = [w["blocks"][i].in_len for i in idx]
+        orders = [w["blocks"][i].order for i in idx]
+        blocks, in_bytes, out_bytes = xc.Engine.plan_encode(lens, orders)
+        h_in, h_out, h_len = L.cramgpu_host_alloc(in_bytes), L.cramgpu_host_alloc(out_bytes), L.cramgpu_host_alloc(4 * len(lens))
+        h_pos = L.cramgpu_host_alloc(8 * (len(lens) + 1))
+        assert h_in and h_out and h_len and h_pos, "cramgpu_host_alloc failed"
+        arena = torch.from_numpy(np.ctypeslib.as_array(C.cast(h_in, C.POINTER(C.c_uint8)), shape=(in_bytes,)))
+        # the job's input arena has the same back-to-back layout as the slice of the device arena it comes from
+        b0, bl = w["blocks"][idx[0]], w["blocks"][idx[-1]]
+        assert blocks[len(lens) - 1].in_off == bl.in_off - b0.in_off
+        arena[:bl.in_off - b0.in_off + bl.in_len] = d_in[b0.in_off:bl.in_off + bl.in_len].cpu()
+        jobs.append((blocks, in_bytes, out_bytes, h_in, h_out, h_len, len(lens), sum(lens), h_pos))
+
+    def run():
+        pending, raw, comp = [], 0, 0
+        t0 = time.perf_counter()
+        for (blocks, in_bytes, out_bytes, h_in, h_out, h_len, n, rb, h_pos) in jobs:
+            if len(pending) == outstanding:
+                j, hl, nn = pending.pop(0)
+                _lib.check(L.cramgpu_job_wait(j))
+                comp += int(np.ctypeslib.as_array(C.cast(hl, C.POINTER(C.c_int32)), shape=(nn,)).sum())
+            if packed:
+                j = L.cramgpu_rans_submit_packed(eng.handle, h_in, in_bytes, h_out, out_bytes, C.addressof(blocks), n, h_len, h_pos)
+            else:
+                j = L.cramgpu_rans_submit(eng.handle, 0, h_in, in_bytes, h_out, out_bytes, C.addressof(blocks), n, h_len)
+            assert j, _lib.last_error()
+            pending.append((j, h_len, n))
+            raw += rb
+        for j, hl, nn in pending:
+            _lib.check(L.cramgpu_job_wait(j))
+            comp += int(np.ctypeslib.as_array(C.cast(hl, C.POINTER(C.c_int32)), shape=(nn,)).sum())
+        return time.perf_counter() - t0, raw, comp
+    run()
+    best = min(run() for _ in range(reps))
+    # spot check: the first job's first stream came back where the synchronous path puts it
+    blocks, _, _, h_in, h_out, h_len, n, _, _ = jobs[0]
+    first_len = int(np.ctypeslib.as_array(C.cast(h_len, C.POINTER(C.c_int32)), shape=(n,))[0])
+    head = bytes(np.ctypeslib.as_array(C.cast(h_out, C.POINTER(C.c_uint8)), shape=(9,)))
+    assert head[0] == blocks[0].order and int.from_bytes(head[5:9], "little") == blocks[0].in_len and first_len > 9
+    for (_, _, _, h_in, h_out, h_len, _, _, h_pos) in jobs:
+        L.cramgpu_host_free(h_in), L.cramgpu_host_free(h_out), L.cramgpu_host_free(h_len), L.cramgpu_host_free(h_pos)
+    dt, raw, comp = best
+    return dict(value=raw / dt / 1e6, unit="MB/s", entry_point="cramgpu_rans_submit_packed" if packed else "cramgpu_rans_submit",
+                containers_per_job=per_job, jobs_outstanding=outstanding,
+                containers=n_cont, ms=dt * 1e3, raw_MB=raw / 1e6, compressed_MB=comp / 1e6,
+                note="raw blocks from pinned host arenas, streams back into pinned host arenas (H2D + kernels + D2H)")
+
+
 def pmc_traffic(a):
     """HBM bytes per rans_encode_kernel launch from the committed rocprofv3 --pmc passes (profiles/*_pmc_*.csv, taken
     with this same command at the default sizes): 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of 16-byte
@@ -382,6 +443,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -445,6 +507,8 @@ def main():
                                    ms_per_step=dec_s * 1e3, rans_decode_kernel_ms=k2_s * 1e3,
                                    rans_decode_GBps=algo / k2_s / 1e9, rans_decode_frac_of_hbm=algo / k2_s / 1e9 / HBM_PEAK_GBS,
                                    parity=dec_parity)
+        if not a.no_pcie and world == 1:
+            extra["pcie_inclusive"] = pcie_inclusive(eng, w)
         total_raw = w["raw_bytes"] * world
         line = dict(metric="CRAM encode hot path: uncompressed external-block payload MB/s (rANS o0/o1 + feature extraction)",
                     value=total_raw * a.steps / dt / 1e6, unit="MB/s", n_gpus=world, steps=a.steps, warmup=a.warmup,

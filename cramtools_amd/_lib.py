@@ -115,6 +115,7 @@ SYMBOLS = {
     "cramgpu_host_alloc": (P, [I64]),
     "cramgpu_host_free": (None, [P]),
     "cramgpu_rans_submit": (P, [P, I32, P, I64, P, I64, P, I32, P]),
+    "cramgpu_rans_submit_packed": (P, [P, P, I64, P, I64, P, I32, P, P]),
     "cramgpu_job_poll": (I32, [P]),
     "cramgpu_job_wait": (I32, [P]),
     "cramgpu_extract_features_dev": (I64, [P, P, P, P, P, P]),

@@ -142,8 +142,14 @@ struct cramgpu_job {
     DevBuf<int32_t> d_len;
     DevBuf<int64_t> d_pos;
     PinBuf<int32_t> h_len;
-    PinBuf<int64_t> h_pos;
+    PinBuf<int64_t> h_pos;       // encode: start of every stream in the packed arena (n + 1 entries)
+    DevBuf<uint8_t> d_pack;      // encode: the streams packed back to back (what crosses PCIe)
+    DevBuf<int64_t> d_off;
+    DevBuf<int32_t> d_err;
+    int64_t out_bytes = 0, span_lo = 0, span_hi = 0;
+    int64_t* out_pos = nullptr;  // cramgpu_rans_submit_packed: the streams stay packed, their starts go here
     hipEvent_t coded = nullptr, done = nullptr;  // lengths on the host / streams in the caller's arena
+    hipEvent_t uploaded = nullptr;               // input arena on the device (recorded on the context's upload stream)
 };
 
 // Small host tables (code tables, policies) on their way to the device: a ring of pinned slots, each with its own
@@ -168,6 +174,10 @@ struct cramgpu_ctx {
     hipStream_t last_stream = nullptr;
     bool last_valid = false;
     uint8_t* static_scratch = nullptr;  // this device's address of `scratch` (cramgpu_rans_encode_static)
+    // Input arenas of asynchronous jobs go up on ONE stream, in submission order: copies queued on the jobs' own streams
+    // share the PCIe link, all finish together (four 425 MB uploads: all at 29 ms) and no kernel starts before that;
+    // first come, first served lets job k's kernels run under job k+1's upload.
+    hipStream_t upload_stream = nullptr;
     // reference contigs of the host-form level-2 calls (cramgpu_ref_upload) and their ReferenceTracks window positions
     struct Contig {
         DevBuf<uint8_t> d;
@@ -290,7 +300,22 @@ int rans_run(cramgpu_ctx* c, LaunchRes& r, bool encode, const uint8_t* d_in, uin
     if (rc) return rc;
     // resident workgroups of this launch and their global scratch (grown on demand: a job of a few containers needs
     // a few workgroups' worth, the synchronous calls of a whole read set all of them)
-    const int groups = std::min(n, encode ? c->n_waves_enc : c->n_waves_dec);
+    // Resident workgroups of this launch.  A block is one serial chain, so the launch cannot end before its longest block
+    // does: more workgroups than (total work / longest block) only hold LDS and wave slots that the launches of other
+    // job slots could use (a job of 256 containers has 256 long blocks among 2560: 1024 workgroups of it kept the next
+    // job's kernel waiting for a whole chain latency).  Work of a block ~ its bytes + a fixed cost of ~40 KB worth.
+    int groups = std::min(n, encode ? c->n_waves_enc : c->n_waves_dec);
+    {
+        const int64_t fixed = 40 * 1024;
+        int64_t total = 0, longest = 1;
+        for (int32_t i = 0; i < n; i++) {
+            const int64_t w = (int64_t)blocks[i].in_len * (encode ? 1 : 4) + fixed;  // a stream decodes to ~4-8x its size
+            total += w;
+            longest = std::max(longest, w);
+        }
+        const int64_t need = (total + longest - 1) / longest;
+        groups = (int)std::min<int64_t>(groups, need + need / 8 + 8);
+    }
     HIPCHK(r.tickets.reserve(kTicketSlots));
     if (encode)
         HIPCHK(r.enc_gs.reserve((size_t)groups * ENC_GSCRATCH_BYTES));
@@ -337,6 +362,37 @@ int rans_run(cramgpu_ctx* c, LaunchRes& r, bool encode, const uint8_t* d_in, uin
         HIPCHK(launch_rans_decode(a, groups, c->dec_lds, s));
     }
     return 0;
+}
+
+// a free job slot of the context, its stream and events created on first use
+cramgpu_job* grab_job(cramgpu_ctx* c, int kind) {  // under c->mu
+    cramgpu_job* j = nullptr;
+    for (auto& cand : c->jobs)
+        if (!cand.busy) {
+            j = &cand;
+            break;
+        }
+    if (!j) {
+        fail(CRAMGPU_E_ARG, "submit: CRAMGPU_MAX_JOBS jobs outstanding, wait for one first");
+        return nullptr;
+    }
+    auto ok = [&](hipError_t e) { return e == hipSuccess || (fail(CRAMGPU_E_HIP, hipGetErrorString(e)), false); };
+    if (!ok(hipSetDevice(c->device))) return nullptr;
+    if (!j->coded && !(ok(hipEventCreateWithFlags(&j->coded, hipEventDisableTiming)) &&
+                       ok(hipEventCreateWithFlags(&j->done, hipEventDisableTiming)) &&
+                       ok(hipEventCreateWithFlags(&j->uploaded, hipEventDisableTiming)) &&
+                       ok(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking))))
+        return nullptr;
+    if (!c->upload_stream && !ok(hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking))) return nullptr;
+    j->ctx = c;
+    j->kind = kind;
+    j->fetched = false;
+    j->early_rc = 0;
+    j->back.clear();
+    j->h_total = nullptr;
+    j->h_feat_count = nullptr;
+    j->feat_cap = 0;
+    return j;
 }
 
 std::mutex g_default_mu;
@@ -441,11 +497,14 @@ void cramgpu_close(cramgpu_ctx* c) {
         j.arena.release();
         j.pin.release();
         j.d_in.release(); j.d_out.release(); j.d_len.release(); j.d_pos.release(); j.h_len.release(); j.h_pos.release();
+        j.d_pack.release(); j.d_off.release(); j.d_err.release();
         j.res.release();
         if (j.stream) (void)hipStreamDestroy(j.stream);
+        if (j.uploaded) (void)hipEventDestroy(j.uploaded);
         if (j.coded) (void)hipEventDestroy(j.coded);
         if (j.done) (void)hipEventDestroy(j.done);
     }
+    if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -616,58 +675,85 @@ void cramgpu_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }
 
-cramgpu_job* cramgpu_rans_submit(cramgpu_ctx* c, int32_t decode, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
-                                 int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len) {
+static cramgpu_job* rans_submit(cramgpu_ctx* c, int32_t decode, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                                int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len, int64_t* out_pos) {
     if (!c || n <= 0 || in_bytes < 0 || out_bytes < 0 || !in_arena || !out_arena || !blocks || !out_len) {
         fail(CRAMGPU_E_ARG, "submit: bad argument");
         return nullptr;
     }
-    for (int32_t i = 0; i < n; i++)
+    int64_t max_cap = 0, lo = out_bytes, hi = 0, prev_end = 0;
+    for (int32_t i = 0; i < n; i++) {
         if (blocks[i].in_off + blocks[i].in_len > in_bytes || blocks[i].out_off + blocks[i].out_cap > out_bytes) {
             fail(CRAMGPU_E_ARG, "submit: block outside its arena");
             return nullptr;
         }
-    std::lock_guard<std::mutex> lk(c->mu);
-    cramgpu_job* j = nullptr;
-    for (auto& cand : c->jobs)
-        if (!cand.busy) {
-            j = &cand;
-            break;
+        // the streams come back packed and are spread to their slots from the last one down, in place: the slots have
+        // to lie in ascending order without overlap (Engine.plan_encode / any back-to-back layout)
+        if (!decode && !out_pos && blocks[i].out_off < prev_end) {
+            fail(CRAMGPU_E_ARG, "submit: output slots must be ascending and must not overlap");
+            return nullptr;
         }
-    if (!j) {
-        fail(CRAMGPU_E_ARG, "submit: CRAMGPU_MAX_JOBS jobs outstanding, wait for one first");
-        return nullptr;
+        prev_end = blocks[i].out_off + blocks[i].out_cap;
+        max_cap = std::max<int64_t>(max_cap, blocks[i].out_cap);
+        lo = std::min<int64_t>(lo, blocks[i].out_off);
+        hi = std::max<int64_t>(hi, blocks[i].out_off + blocks[i].out_cap);
     }
+    std::lock_guard<std::mutex> lk(c->mu);
+    cramgpu_job* j = grab_job(c, 0);
+    if (!j) return nullptr;
     auto ok = [&](hipError_t e) { return e == hipSuccess || (fail(CRAMGPU_E_HIP, hipGetErrorString(e)), false); };
-    if (!ok(hipSetDevice(c->device))) return nullptr;
-    if (!j->coded && !(ok(hipEventCreateWithFlags(&j->coded, hipEventDisableTiming)) &&
-                       ok(hipEventCreateWithFlags(&j->done, hipEventDisableTiming)) &&
-                       ok(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking))))
-        return nullptr;
     hipStream_t s = j->stream;  // every job slot has its own stream: the launches of outstanding jobs overlap
     if (!(ok(j->d_in.reserve((size_t)align_up(in_bytes, 16) + 16)) && ok(j->d_out.reserve((size_t)align_up(out_bytes, 16) + 16)) &&
-          ok(j->d_len.reserve(n)) && ok(j->d_pos.reserve(n)) && ok(j->h_len.reserve(n)) && ok(j->h_pos.reserve(n))))
+          ok(j->d_len.reserve(n)) && ok(j->d_pos.reserve(n)) && ok(j->h_len.reserve(n)) && ok(j->h_pos.reserve((size_t)n + 1))))
         return nullptr;
-    j->ctx = c;
-    j->kind = 0;
     j->decode = decode != 0;
-    j->fetched = false;
     j->n = n;
     j->out_arena = out_arena;
     j->out_len = out_len;
+    j->out_bytes = out_bytes;
+    j->out_pos = out_pos;
+    j->span_lo = lo;
+    j->span_hi = hi;
     j->blocks.assign(blocks, blocks + n);
-    if (!ok(hipMemcpyAsync(j->d_in.p, in_arena, (size_t)in_bytes, hipMemcpyHostToDevice, s))) return nullptr;
+    if (!(ok(hipMemcpyAsync(j->d_in.p, in_arena, (size_t)in_bytes, hipMemcpyHostToDevice, c->upload_stream)) &&
+          ok(hipEventRecord(j->uploaded, c->upload_stream)) && ok(hipStreamWaitEvent(s, j->uploaded, 0))))
+        return nullptr;
     if (rans_run(c, j->res, !j->decode, j->d_in.p, j->d_out.p, blocks, n, j->d_len.p, j->decode ? nullptr : j->d_pos.p, s))
         return nullptr;
     if (!ok(hipMemcpyAsync(j->h_len.p, j->d_len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s))) return nullptr;
-    if (!j->decode && !ok(hipMemcpyAsync(j->h_pos.p, j->d_pos.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, s)))
-        return nullptr;
+    if (!j->decode) {
+        // pack on the device: one copy instead of one per block brings the streams back (2560 small copies of a
+        // 256-container job cost more host time than the job's kernels took)
+        if (!(ok(j->d_pack.reserve((size_t)align_up(out_bytes, 16) + 16)) && ok(j->d_off.reserve((size_t)n + 1)) &&
+              ok(j->d_err.reserve(16))))
+            return nullptr;
+        if (!ok(launch_gather(j->d_out.p, j->d_pos.p, j->d_len.p, n, 16, j->d_pack.p, out_bytes, j->d_off.p, j->d_err.p,
+                              (int32_t)std::min<int64_t>(max_cap, 0x7fffffff), s)))
+            return nullptr;
+        if (!ok(hipMemcpyAsync(j->h_pos.p, j->d_off.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s))) return nullptr;
+    }
     if (!ok(hipEventRecord(j->coded, s))) return nullptr;
     j->busy = true;
     return j;
 }
 
-// second half of a job: once the lengths are on the host, one copy per block into the caller's arena
+cramgpu_job* cramgpu_rans_submit(cramgpu_ctx* c, int32_t decode, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                                 int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len) {
+    return rans_submit(c, decode, in_arena, in_bytes, out_arena, out_bytes, blocks, n, out_len, nullptr);
+}
+
+cramgpu_job* cramgpu_rans_submit_packed(cramgpu_ctx* c, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                                        int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len,
+                                        int64_t* out_pos) {
+    if (!out_pos) {
+        fail(CRAMGPU_E_ARG, "submit_packed: out_pos missing");
+        return nullptr;
+    }
+    return rans_submit(c, 0, in_arena, in_bytes, out_arena, out_bytes, blocks, n, out_len, out_pos);
+}
+
+// second half of a job: once the lengths are on the host, ONE copy brings the results into the caller's arena —
+// the packed streams (encode; spread to their slots by job_wait) or the span of the raw blocks (decode)
 static int job_fetch(cramgpu_job* j) {
     if (j->fetched) return 0;
     cramgpu_ctx* c = j->ctx;
@@ -687,12 +773,15 @@ static int job_fetch(cramgpu_job* j) {
         j->fetched = true;
         return 0;
     }
-    for (int32_t i = 0; i < j->n; i++) {
-        const int32_t len = j->h_len.p[i];
-        j->out_len[i] = len;
-        if (len <= 0) continue;
-        const uint8_t* src = j->d_out.p + (j->decode ? j->blocks[i].out_off : j->h_pos.p[i]);
-        HIPCHK(hipMemcpyAsync(j->out_arena + j->blocks[i].out_off, src, (size_t)len, hipMemcpyDeviceToHost, j->stream));
+    for (int32_t i = 0; i < j->n; i++) j->out_len[i] = j->h_len.p[i];
+    if (j->decode) {
+        if (j->span_hi > j->span_lo)
+            HIPCHK(hipMemcpyAsync(j->out_arena + j->span_lo, j->d_out.p + j->span_lo, (size_t)(j->span_hi - j->span_lo),
+                                  hipMemcpyDeviceToHost, j->stream));
+    } else {
+        const int64_t packed = j->h_pos.p[j->n];
+        if (packed > j->out_bytes) return fail(CRAMGPU_E_INSUFFICIENT, "job: packed streams exceed the output arena");
+        if (packed > 0) HIPCHK(hipMemcpyAsync(j->out_arena, j->d_pack.p, (size_t)packed, hipMemcpyDeviceToHost, j->stream));
     }
     HIPCHK(hipEventRecord(j->done, j->stream));
     j->fetched = true;
@@ -723,6 +812,17 @@ int32_t cramgpu_job_wait(cramgpu_job* j) {
         if (e != hipSuccess) rc = fail(CRAMGPU_E_HIP, hipGetErrorString(e));
     }
     if (!rc && j->kind != 0) rc = j->early_rc;
+    if (!rc && j->kind == 0 && !j->decode && j->out_pos) {
+        memcpy(j->out_pos, j->h_pos.p, ((size_t)j->n + 1) * sizeof(int64_t));
+    } else if (!rc && j->kind == 0 && !j->decode) {
+        // spread the packed streams to the starts of their slots, last one first: stream i sits at or below its slot and
+        // everything that still has to move lies below it
+        for (int32_t i = j->n - 1; i >= 0; i--) {
+            const int32_t len = j->h_len.p[i];
+            if (len > 0 && j->blocks[i].out_off != j->h_pos.p[i])
+                memmove(j->out_arena + j->blocks[i].out_off, j->out_arena + j->h_pos.p[i], (size_t)len);
+        }
+    }
     j->busy = false;  // the slot (and its device buffers) can take the next submission
     return rc;
 }
@@ -1085,34 +1185,6 @@ struct Carver {
         return p;
     }
 };
-
-cramgpu_job* grab_job(cramgpu_ctx* c, int kind) {  // under c->mu
-    cramgpu_job* j = nullptr;
-    for (auto& cand : c->jobs)
-        if (!cand.busy) {
-            j = &cand;
-            break;
-        }
-    if (!j) {
-        fail(CRAMGPU_E_ARG, "submit: CRAMGPU_MAX_JOBS jobs outstanding, wait for one first");
-        return nullptr;
-    }
-    auto ok = [&](hipError_t e) { return e == hipSuccess || (fail(CRAMGPU_E_HIP, hipGetErrorString(e)), false); };
-    if (!ok(hipSetDevice(c->device))) return nullptr;
-    if (!j->coded && !(ok(hipEventCreateWithFlags(&j->coded, hipEventDisableTiming)) &&
-                       ok(hipEventCreateWithFlags(&j->done, hipEventDisableTiming)) &&
-                       ok(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking))))
-        return nullptr;
-    j->ctx = c;
-    j->kind = kind;
-    j->fetched = false;
-    j->early_rc = 0;
-    j->back.clear();
-    j->h_total = nullptr;
-    j->h_feat_count = nullptr;
-    j->feat_cap = 0;
-    return j;
-}
 
 // windows of the containers of a stripe: the whole contig, or the caller's region clipped to it.  The reference arena
 // argument of the record kernels is the null pointer and ref_off the contig's device ADDRESS: contigs are separate

@@ -144,22 +144,31 @@ int32_t cramgpu_rans_decode_batch(cramgpu_ctx* ctx, const uint8_t* in_arena, int
 
 /* Asynchronous form of the host-buffer batch: what TransformerJob threads (paralell/TransformerJob.java:16-41) and
  * CRAMContainerAsynchWriter.Batch.run (CRAMContainerAsynchWriter.java:139-149) do with a thread per container, the
- * library does with a queue per context: cramgpu_rans_submit copies the input arena to the GPU, codes the blocks and
- * fetches lengths with hipMemcpyAsync on the job slot's own stream and returns at once; the Java thread marshals the
- * next container meanwhile.  cramgpu_job_wait brings the streams into out_arena (as cramgpu_rans_*_batch leaves
- * them) and out_len, and releases the job; cramgpu_job_poll says whether wait would block (1 = finished).
+ * library does with a queue per context: cramgpu_rans_submit copies the input arena to the GPU, codes the blocks,
+ * packs the streams on the device and fetches lengths with hipMemcpyAsync on the job slot's own stream and returns at
+ * once; the Java thread marshals the next container meanwhile.  cramgpu_job_wait brings the streams into out_arena (as
+ * cramgpu_rans_*_batch leaves them: ONE copy of the packed streams, spread to their slots on the host; encode slots
+ * must therefore be ascending and non-overlapping) and out_len, and releases the job; cramgpu_job_poll says whether
+ * wait would block (1 = finished).
  * (cramgpu_job_poll / cramgpu_job_wait also serve the jobs of cramgpu_submit_reads / cramgpu_submit_restore.)
  * Arenas and out_len must stay valid and untouched from submit to wait; for copies that overlap host work they
  * should come from cramgpu_host_alloc (pinned memory, exposed to Java as direct ByteBuffers).  At most
  * CRAMGPU_MAX_JOBS may be outstanding per context (submit fails with CRAMGPU_E_ARG beyond); every slot has its own
  * stream and launch resources, so the copies and kernels of outstanding jobs overlap.  One context per GPU. */
-#define CRAMGPU_MAX_JOBS 4
+#define CRAMGPU_MAX_JOBS 16
 typedef struct cramgpu_job cramgpu_job;
 void* cramgpu_host_alloc(int64_t bytes);
 void cramgpu_host_free(void* p);
 cramgpu_job* cramgpu_rans_submit(cramgpu_ctx* ctx, int32_t decode, const uint8_t* in_arena, int64_t in_bytes,
                                  uint8_t* out_arena, int64_t out_bytes, const cramgpu_block* blocks, int32_t n_blocks,
                                  int32_t* out_len);
+/* The encode form a JNI host wants: the streams STAY packed back to back (16-byte aligned starts) from the beginning
+ * of out_arena and out_pos (int64[n_blocks + 1]) receives their starts after the wait; Block.setContent copies each
+ * stream into its own byte[] anyway, so nothing is gained by spreading them to slots on the host first.  blocks[b]
+ * .out_off is ignored beyond sizing (out_cap is the slot the kernels code into on the device). */
+cramgpu_job* cramgpu_rans_submit_packed(cramgpu_ctx* ctx, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                                        int64_t out_bytes, const cramgpu_block* blocks, int32_t n_blocks, int32_t* out_len,
+                                        int64_t* out_pos);
 int32_t cramgpu_job_poll(cramgpu_job* job);
 int32_t cramgpu_job_wait(cramgpu_job* job);
 

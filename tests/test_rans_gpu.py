@@ -108,11 +108,11 @@ def test_corrupt_streams_do_not_crash(engine, orc):
 
 def test_async_jobs(engine, orc):
     """cramgpu_rans_submit / poll / wait: several containers' worth of blocks queued before the first wait give what
-    the synchronous batch gives; a fifth outstanding job is refused; decode jobs round-trip."""
+    the synchronous batch gives; one more job than CRAMGPU_MAX_JOBS (16) is refused; decode jobs round-trip."""
     rng = np.random.default_rng(3)
     batches = []
-    for k in range(4):
-        datas = [rng.integers(0, 5 + 40 * k, n, dtype=np.uint8).tobytes() for n in (30000 + k, 777, 5, 12000)]
+    for k in range(16):
+        datas = [rng.integers(0, 5 + 15 * k, n, dtype=np.uint8).tobytes() for n in (3000 + k, 777, 5, 1200)]
         batches.append((datas, [1, 0, 1, 1]))
     jobs = [engine.submit_compress(d, o) for d, o in batches]
     from cramtools_amd._lib import CramGpuError
