@@ -165,6 +165,8 @@ def lib():
         prof = os.path.join(_HERE, "libcramgpu_prof.so")  # make -C cramtools_amd/csrc prof: in-kernel cycle stamps
         if os.environ.get("CRAMGPU_PROF") == "1" and os.path.exists(prof):
             path = prof
+        if os.environ.get("CRAMGPU_LIB"):  # development: another build of the same library (kernel experiments)
+            path = os.environ["CRAMGPU_LIB"]
         L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

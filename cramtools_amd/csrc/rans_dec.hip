@@ -33,7 +33,9 @@ struct DecFixedLds {
     uint8_t present[256];
     uint16_t nsym[256];      // symbols listed by context (byte) i
     uint32_t rowinfo[256];   // ragged rows: entry offset | 16-entry units << 24, by dense context
+    uint8_t stage[1024];     // narrow order-1 path: dense symbols of 256 steps x 4 states, flushed 16 bytes per lane
 };
+static_assert(sizeof(DecFixedLds) % 64 == 0, "tables behind the fixed part start on a 64-byte boundary");
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
 __device__ __forceinline__ uint32_t mbcnt2(unsigned long long m1, unsigned long long m2) {
@@ -336,7 +338,7 @@ __device__ __forceinline__ void rows_fix(uint32_t* rows, int nd, int stride) {
 }
 
 // D04#uncompress L9-85.  R[4096]: sym | (F-1)<<8 | (slot-C)<<20.  State g = lanes 16g..16g+15.
-__device__ int decode_o0(Stream& S, int32_t p, const uint32_t* R, uint8_t* out, int32_t n) {
+__device__ __forceinline__ int decode_o0(Stream& S, int32_t p, const uint32_t* R, uint8_t* out, int32_t n) {
     const int l = lane_id();
     const int g = l >> 4, s = l & 15;
     if (p + 16 > S.len) return CRAMGPU_E_CORRUPT;
@@ -383,7 +385,7 @@ __device__ int decode_o0(Stream& S, int32_t p, const uint32_t* R, uint8_t* out, 
 // MS > 0: square rows[nd][16*MS], MS known at compile time (the next row is fetched while the state renormalises).
 // MS == 0: ragged rows (FillRagged): rowinfo[k] = entry offset | 16-entry units << 24 of context k's row.
 template <int MS>
-__device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, const uint32_t* rowinfo, const uint8_t* syml,
+__device__ __forceinline__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, const uint32_t* rowinfo, const uint8_t* syml,
                          uint8_t* out, int32_t n) {
     const int l = lane_id();
     const int g = l >> 4, s = l & 15;
@@ -473,7 +475,290 @@ __device__ int decode_o1(Stream& S, int32_t p, const uint32_t* rows, const uint3
     return 0;
 }
 
-__device__ void decode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* gs) {
+
+// ---- order 1 over a dense alphabet of at most 16 symbols (quality series): the narrow path ----
+// An entry is  (4096 - C) & 4095 in bits 20..31 | F << 7 | symbol << 2  (F = 1..4096 in 13 bits), so that
+//   v = (x << 20) + entry
+// carries (slot - C) mod 4096 in its top 12 bits.  The symbol the slot belongs to is the one with the largest C <= slot:
+// its (slot - C) is the smallest of the row (a symbol with C > slot wraps to 4096 - (C - slot), which is larger), so an
+// unsigned MIN butterfly over the row delivers the winner's word: slot - C on top, F and the symbol below — one
+// instruction per lane instead of a five-instruction range test, and no select.  Symbols a context does not have carry a
+// copy of one it has.
+//   SMALL (alphabet <= 8): ent[symbol][context] (8 x 8 words); lanes 8..15 of a row mirror lanes 0..7, three butterfly
+//     stages, and the next entry's address is one v_and_or (symbol << 2 selects the word in the lane's own 32 bytes);
+//   otherwise (<= 16):     ent[context][symbol] (16 x 16 words), four stages.
+// The main loop is hand-scheduled (narrow_block): 256 steps per call, decoded symbols pushed through a DPP shift
+// register and staged in LDS, flushed as one 16-byte store per lane (a byte store per 16 steps kept the vector-memory
+// counter busy: the next renormalisation's wait for its window also waited for that store).
+struct FillNarrow {
+    uint32_t* ent;
+    const uint8_t* dmap;
+    int ctx_stride, sym_stride;  // words
+    int cur;
+    __device__ __forceinline__ void ctx(int i) { cur = dmap[i] * ctx_stride; }
+    __device__ __forceinline__ void sym(int j, int F, int C) {
+        if (lane_id() == 0)
+            ent[cur + dmap[j] * sym_stride] =
+                (((4096u - (uint32_t)C) & 4095u) << 20) | ((uint32_t)F << 7) | ((uint32_t)dmap[j] << 2);
+    }
+};
+// every absent entry of a context becomes a copy of the context's first present entry (0 for a context the table
+// never defined, reachable from a corrupt stream only: it decodes to garbage without leaving the tables)
+__device__ __forceinline__ void narrow_fix(uint32_t* ent, int nsl, int ctx_stride, int sym_stride) {
+    const int c = lane_id();
+    if (c < nsl) {
+        uint32_t first = 0;
+        for (int j = nsl - 1; j >= 0; j--) {
+            const uint32_t v = ent[c * ctx_stride + j * sym_stride];
+            if (v != kAbsent) first = v;
+        }
+        for (int j = 0; j < nsl; j++)
+            if (ent[c * ctx_stride + j * sym_stride] == kAbsent) ent[c * ctx_stride + j * sym_stride] = first;
+    }
+}
+
+template <bool SMALL>
+__device__ __forceinline__ uint32_t row_min(uint32_t v) {
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v = t < v ? t : v;
+    if (!SMALL) {
+        t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+struct __attribute__((packed)) PackedU128 { uint32_t a, b, c, d; };
+
+// stage[g][256] (dense symbols of steps i0 .. i0+255 of state g) -> out[g * q + i0 ...], 16 bytes per lane
+__device__ __forceinline__ void flush_stage(const uint8_t* stage, const uint8_t* syml, uint8_t* out, int32_t q, int32_t i0) {
+    const int l = lane_id();
+    const int g = l >> 4, part = l & 15;
+    const uint4 raw = *reinterpret_cast<const uint4*>(stage + g * 256 + part * 16);
+    const uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        o[c] = (uint32_t)syml[r[c] & 255u] | ((uint32_t)syml[(r[c] >> 8) & 255u] << 8) |
+               ((uint32_t)syml[(r[c] >> 16) & 255u] << 16) | ((uint32_t)syml[r[c] >> 24] << 24);
+    *reinterpret_cast<PackedU128*>(out + (size_t)g * q + i0 + part * 16) = PackedU128{o[0], o[1], o[2], o[3]};
+}
+
+#ifndef HIP_SIM
+// One decode step of the narrow path.  KW: the register this step's winner word is written to, KO: the other one of the
+// pair (it holds the previous step's word in every lane; the row_shr:1 move turns it into the shift register of the
+// chunk's words, lane j = j steps ago).  A DPP source may not be read by the instruction right after the one that wrote
+// it: the two independent instructions of the step (x >> 12, the shift-register move) fill two of those slots.
+#define NB_MIN(DST, CTRL) "v_min_u32_dpp %[" DST "], %[v], %[v] " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#ifdef NB_LATE_FILL
+#define NB_FILL1 "s_nop 0\n\t"
+#define NB_FILL2(KW, KO) "s_nop 0\n\t"
+#define NB_LATE(KW, KO)                                                                    \
+    "v_mov_b32_dpp %[" KW "], %[" KO "] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"           \
+    "v_lshrrev_b32 %[xs], 12, %[x]\n\t"
+#define NB_LAST_PUSH
+#else
+#define NB_FILL1 "v_lshrrev_b32 %[xs], 12, %[x]\n\t"
+#define NB_FILL2(KW, KO) "v_mov_b32_dpp %[" KO "], %[" KW "] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define NB_LATE(KW, KO)
+#define NB_LAST_PUSH "v_mov_b32_dpp %[k1], %[k0] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#endif
+#define NB_BUTTERFLY_SMALL(KW, KO)                                                         \
+    NB_FILL1                                                                                \
+    NB_MIN("v", "quad_perm:[1,0,3,2]")                                                      \
+    NB_FILL2(KW, KO)                                                                        \
+    NB_MIN("v", "quad_perm:[2,3,0,1]")                                                      \
+    "s_nop 0\n\t"                                                                           \
+    NB_MIN(KW, "row_half_mirror")                                                           \
+    "v_and_or_b32 %[t], %[" KW "], 28, %[lb]\n\t"
+#define NB_BUTTERFLY_MID(KW, KO)                                                           \
+    NB_FILL1                                                                                \
+    NB_MIN("v", "quad_perm:[1,0,3,2]")                                                      \
+    NB_FILL2(KW, KO)                                                                        \
+    NB_MIN("v", "quad_perm:[2,3,0,1]")                                                      \
+    "s_nop 0\n\t"                                                                           \
+    NB_MIN("v", "row_half_mirror")                                                          \
+    "s_nop 0\n\t"                                                                           \
+    NB_MIN(KW, "row_mirror")                                                                \
+    "v_and_b32 %[t], 60, %[" KW "]\n\t"                                                     \
+    "v_lshl_add_u32 %[t], %[t], 4, %[lb]\n\t"
+#define NB_STEP(N, BUTTERFLY, KW, KO)                                                      \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                              \
+    "v_lshl_add_u32 %[v], %[x], 20, %[e]\n\t"                                               \
+    BUTTERFLY(KW, KO)                                                                       \
+    "ds_read_b32 %[e], %[t]\n\t"                                                            \
+    "v_lshrrev_b32 %[d], 20, %[" KW "]\n\t"                                                 \
+    "v_bfe_u32 %[f], %[" KW "], 7, 13\n\t"                                                  \
+    NB_LATE(KW, KO)                                                                         \
+    "v_mad_u32_u24 %[x], %[f], %[xs], %[d]\n\t"                                             \
+    "v_cmp_gt_u32_e32 vcc, 0x800000, %[x]\n\t"                                              \
+    "s_cbranch_vccz .Ldone" #N "_%=\n\t"                                                    \
+    "v_cmp_gt_u32_e64 %[n2], %[c15], %[x]\n\t"                                              \
+    "v_cndmask_b32_e32 %[sel], %[selno], %[selone], vcc\n\t"                                \
+    "s_and_b64 vcc, vcc, %[ktop]\n\t"                                                       \
+    "v_mbcnt_lo_u32_b32 %[a], vcc_lo, 0\n\t"                                                \
+    "v_mbcnt_hi_u32_b32 %[a], vcc_hi, %[a]\n\t"                                             \
+    "s_bcnt1_i32_b64 %[stot], vcc\n\t"                                                      \
+    "s_waitcnt vmcnt(0)\n\t"                                                                \
+    "v_alignbyte_b32 v102, v101, v100, %[a]\n\t"                                            \
+    "s_cmp_lg_u64 %[n2], 0\n\t"                                                             \
+    "s_cbranch_scc1 .Ltwo" #N "_%=\n\t"                                                     \
+    ".Lapply" #N "_%=:\n\t"                                                                 \
+    "v_perm_b32 %[x], %[x], v102, %[sel]\n\t"                                               \
+    "v_add_u32 %[curv], %[stot], %[curv]\n\t"                                               \
+    "global_load_dwordx2 v[100:101], %[curv], %[sb]\n\t"                                    \
+    ".Ldone" #N "_%=:\n\t"
+// the rare case: some state needs a second byte (it decoded a symbol of frequency < 16)
+#define NB_TWO(N)                                                                          \
+    ".Ltwo" #N "_%=:\n\t"                                                                   \
+    "s_mov_b64 vcc, %[n2]\n\t"                                                              \
+    "v_cndmask_b32_e32 %[sel], %[sel], %[seltwo], vcc\n\t"                                  \
+    "s_and_b64 vcc, vcc, %[ktop]\n\t"                                                       \
+    "v_mbcnt_lo_u32_b32 %[a], vcc_lo, %[a]\n\t"                                             \
+    "v_mbcnt_hi_u32_b32 %[a], vcc_hi, %[a]\n\t"                                             \
+    "s_bcnt1_i32_b64 %[s2], vcc\n\t"                                                        \
+    "s_add_u32 %[stot], %[stot], %[s2]\n\t"                                                 \
+    "v_lshlrev_b32 %[a], 3, %[a]\n\t"                                                       \
+    "v_lshrrev_b64 v[102:103], %[a], v[100:101]\n\t"                                        \
+    "s_branch .Lapply" #N "_%=\n\t"
+#define NB_16(M, ...)                                                                      \
+    M(0, __VA_ARGS__, "k0", "k1") M(1, __VA_ARGS__, "k1", "k0") M(2, __VA_ARGS__, "k0", "k1") M(3, __VA_ARGS__, "k1", "k0")   \
+    M(4, __VA_ARGS__, "k0", "k1") M(5, __VA_ARGS__, "k1", "k0") M(6, __VA_ARGS__, "k0", "k1") M(7, __VA_ARGS__, "k1", "k0")   \
+    M(8, __VA_ARGS__, "k0", "k1") M(9, __VA_ARGS__, "k1", "k0") M(10, __VA_ARGS__, "k0", "k1") M(11, __VA_ARGS__, "k1", "k0") \
+    M(12, __VA_ARGS__, "k0", "k1") M(13, __VA_ARGS__, "k1", "k0") M(14, __VA_ARGS__, "k0", "k1") M(15, __VA_ARGS__, "k1", "k0")
+#define NB_TWOS                                                                            \
+    NB_TWO(0) NB_TWO(1) NB_TWO(2) NB_TWO(3) NB_TWO(4) NB_TWO(5) NB_TWO(6) NB_TWO(7)         \
+    NB_TWO(8) NB_TWO(9) NB_TWO(10) NB_TWO(11) NB_TWO(12) NB_TWO(13) NB_TWO(14) NB_TWO(15)
+#define NB_BODY(BUTTERFLY)                                                                 \
+    "v_mov_b32 v100, %[wlo]\n\t"                                                            \
+    "v_mov_b32 v101, %[whi]\n\t"                                                            \
+    "s_movk_i32 %[cnt], 16\n\t"                                                             \
+    ".Lchunk_%=:\n\t"                                                                       \
+    NB_16(NB_STEP, BUTTERFLY)                                                               \
+    NB_LAST_PUSH                                                                            \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t"                                                       \
+    "v_bfe_u32 %[t], %[k1], 2, 4\n\t"                                                       \
+    "ds_write_b8 %[st], %[t]\n\t"                                                           \
+    "v_add_u32 %[st], 16, %[st]\n\t"                                                        \
+    "s_cmp_lg_u32 %[cnt], 0\n\t"                                                            \
+    "s_cbranch_scc1 .Lchunk_%=\n\t"                                                         \
+    "s_branch .Lend_%=\n\t"                                                                 \
+    NB_TWOS                                                                                 \
+    ".Lend_%=:\n\t"                                                                         \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                     \
+    "v_mov_b32 %[wlo], v100\n\t"                                                            \
+    "v_mov_b32 %[whi], v101\n\t"
+#endif
+
+// 256 steps of all four states.  x: state, e: the lane's entry of the state's context, curv: byte cursor, wlo/whi: the
+// 8 stream bytes at the cursor.  The caller guarantees 256 * 8 + 8 readable bytes behind the cursor.
+template <bool SMALL>
+__device__ __forceinline__ void narrow_block(uint32_t& x, uint32_t& e, uint32_t& curv, uint32_t& wlo, uint32_t& whi,
+                                             uint32_t lane_base, uint32_t stage_addr, const uint8_t* src) {
+#ifndef HIP_SIM
+    uint32_t v, xs, k0 = 0, k1 = 0, t, d, f, a, sel, cnt, stot, s2;
+    unsigned long long n2;
+    const uint32_t selno = 0x07060504u, selone = 0x06050400u, seltwo = 0x05040001u;
+    if (SMALL) {
+        asm volatile(NB_BODY(NB_BUTTERFLY_SMALL)
+                     : [x] "+v"(x), [e] "+v"(e), [curv] "+v"(curv), [wlo] "+v"(wlo), [whi] "+v"(whi), [st] "+v"(stage_addr),
+                       [k0] "+v"(k0), [k1] "+v"(k1), [v] "=&v"(v), [xs] "=&v"(xs), [t] "=&v"(t), [d] "=&v"(d), [f] "=&v"(f),
+                       [a] "=&v"(a), [sel] "=&v"(sel), [cnt] "=&s"(cnt), [stot] "=&s"(stot), [s2] "=&s"(s2), [n2] "=&s"(n2)
+                     : [lb] "v"(lane_base), [sb] "s"(src), [ktop] "s"(kTop), [selno] "v"(selno), [selone] "v"(selone),
+                       [seltwo] "v"(seltwo), [c15] "s"(1u << 15)
+                     : "vcc", "scc", "memory", "v100", "v101", "v102", "v103");
+    } else {
+        asm volatile(NB_BODY(NB_BUTTERFLY_MID)
+                     : [x] "+v"(x), [e] "+v"(e), [curv] "+v"(curv), [wlo] "+v"(wlo), [whi] "+v"(whi), [st] "+v"(stage_addr),
+                       [k0] "+v"(k0), [k1] "+v"(k1), [v] "=&v"(v), [xs] "=&v"(xs), [t] "=&v"(t), [d] "=&v"(d), [f] "=&v"(f),
+                       [a] "=&v"(a), [sel] "=&v"(sel), [cnt] "=&s"(cnt), [stot] "=&s"(stot), [s2] "=&s"(s2), [n2] "=&s"(n2)
+                     : [lb] "v"(lane_base), [sb] "s"(src), [ktop] "s"(kTop), [selno] "v"(selno), [selone] "v"(selone),
+                       [seltwo] "v"(seltwo), [c15] "s"(1u << 15)
+                     : "vcc", "scc", "memory", "v100", "v101", "v102", "v103");
+    }
+#endif
+}
+
+// D14#uncompress L9-70 over narrow tables.  stage: DecFixedLds::stage.
+template <bool SMALL>
+__device__ __forceinline__ int decode_o1_narrow(Stream& S, int32_t p, const uint32_t* ent, uint8_t* stage, const uint8_t* syml, uint8_t* out,
+                                int32_t n) {
+    const int l = lane_id();
+    const int g = l >> 4, s = l & 15;
+    if (p + 16 > S.len) return CRAMGPU_E_CORRUPT;
+    const Payload P{uniform_ptr(S.src), UNIFORM(S.len)};
+    uint32_t x = (uint32_t)P.window(p + 4 * g);
+    int32_t cur = UNIFORM(p) + 16;
+    uint32_t curv = in_vgpr((uint32_t)cur);
+    unsigned long long w = P.window(cur);
+    const int32_t q = n >> 2;
+    const uint32_t* lane_ent = ent + (SMALL ? (s & 7) * 8 : s);  // word k (SMALL) or 16 k of it: this lane's entry in context k
+    uint32_t e = lane_ent[0];
+    auto step = [&](bool live) -> uint32_t {
+        const uint32_t v = row_min<SMALL>((x << 20) + e);
+        if (live) {
+            const uint32_t k = (v >> 2) & 15u;
+            e = lane_ent[SMALL ? k : 16u * k];
+            x = ((v >> 7) & 8191u) * (x >> 12) + (v >> 20);
+        }
+        renorm(x, cur, curv, w, P, live);
+        return (v >> 2) & 15u;
+    };
+    int32_t i = 0;
+    // blocks of 256 steps while the stream has 8 bytes per step and a window left behind the cursor
+    while (i + 256 <= q && cur + 256 * 8 + 8 <= S.len) {
+#ifdef HIP_SIM
+        for (int c = 0; c < 16; c++) {
+            uint32_t keep = 0;
+            for (int j = 0; j < kChunk; j++) keep = row_push(keep, step(true));
+            stage[g * 256 + c * 16 + 15 - s] = (uint8_t)keep;
+        }
+        __syncthreads();
+#else
+        typedef __attribute__((address_space(3))) const void* LdsPtr;
+        uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32);
+        narrow_block<SMALL>(x, e, curv, wlo, whi, (uint32_t)(uintptr_t)(LdsPtr)lane_ent,
+                            (uint32_t)(uintptr_t)(LdsPtr)stage + (uint32_t)(g * 256 + 15 - s), P.src);
+        w = ((unsigned long long)whi << 32) | wlo;
+        cur = UNIFORM(curv);
+#endif
+        flush_stage(stage, syml, out, q, i);
+#ifdef HIP_SIM
+        __syncthreads();
+#endif
+        i += 256;
+    }
+    for (; i + kChunk <= q; i += kChunk) {
+        if (cur > S.len) return CRAMGPU_E_CORRUPT;
+        uint32_t keep = 0;
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) keep = row_push(keep, step(true));
+        out[g * q + i + 15 - s] = syml[keep];
+    }
+    // the last q % 16 common steps, then the n - 4q bytes that only state 3 decodes
+    const int32_t total = q + (n - 4 * q);
+    while (i < total) {
+        if (cur > S.len) return CRAMGPU_E_CORRUPT;
+        const int32_t cnt = total - i < kChunk ? total - i : kChunk;
+        uint32_t keep = 0;
+        for (int j = 0; j < cnt; j++) {
+            const bool live = i + j < q || g == 3;
+            const uint32_t k = step(live);
+            keep = s == j ? k : keep;
+        }
+        if (s < cnt && (i + s < q || g == 3)) out[g * q + i + s] = syml[keep];
+        i += cnt;
+    }
+    if (cur > S.len) return CRAMGPU_E_CORRUPT;
+    return 0;
+}
+
+__device__ __forceinline__ void decode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* gs) {
     const int l = lane_id();
     DecFixedLds* L = reinterpret_cast<DecFixedLds*>(smem);
     uint8_t* tab = smem + sizeof(DecFixedLds);
@@ -553,7 +838,22 @@ __device__ void decode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* g
                     total = __shfl(total, 0);
                     __syncthreads();
                     S.reset();
-                    if (nd <= 48) {  // square rows, 16 * M entries each, always in LDS (<= 9 KiB)
+                    if (nd <= 16) {  // narrow tables: 8 x 8 or 16 x 16 words
+                        const bool small = nd <= 8;
+                        const int nsl = small ? 8 : 16;
+                        uint32_t* r = reinterpret_cast<uint32_t*>(tab);
+                        rows_clear(r, nsl * nsl);
+                        __syncthreads();
+                        FillNarrow v{r, L->dmap, small ? 1 : 16, small ? 8 : 1, 0};
+                        rc = read_rows_o1(S, p, v);
+                        __syncthreads();
+                        if (!rc) {
+                            narrow_fix(r, nsl, small ? 1 : 16, small ? 8 : 1);
+                            __syncthreads();
+                            rc = small ? decode_o1_narrow<true>(S, p, r, L->stage, L->syml, out, raw)
+                                       : decode_o1_narrow<false>(S, p, r, L->stage, L->syml, out, raw);
+                        }
+                    } else if (nd <= 48) {  // square rows, 16 * M entries each, always in LDS (<= 9 KiB)
                         const int M = (nd + 15) >> 4, stride = 16 * M;
                         uint32_t* r = reinterpret_cast<uint32_t*>(tab);
                         rows_clear(r, nd * stride);
@@ -564,9 +864,7 @@ __device__ void decode_block(const RansArgs& a, int b, uint8_t* smem, uint8_t* g
                         if (!rc) {
                             rows_fix(r, nd, stride);
                             __syncthreads();
-                            if (M == 1)
-                                rc = decode_o1<1>(S, p, r, nullptr, L->syml, out, raw);
-                            else if (M == 2)
+                            if (M == 2)
                                 rc = decode_o1<2>(S, p, r, nullptr, L->syml, out, raw);
                             else
                                 rc = decode_o1<3>(S, p, r, nullptr, L->syml, out, raw);

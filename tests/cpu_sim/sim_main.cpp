@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
         const bool quick = argc > 2 && std::string(argv[2]) == "quick";
         const std::vector<int> sizes = quick ? std::vector<int>{1, 3, 4, 5, 17, 63, 100, 700}
                                              : std::vector<int>{1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 255, 1000, 4099, 20000};
-        const std::vector<int> alph = quick ? std::vector<int>{1, 4, 41, 60, 256} : std::vector<int>{1, 2, 4, 8, 41, 57, 90, 256};
+        const std::vector<int> alph = quick ? std::vector<int>{1, 4, 13, 41, 60, 256} : std::vector<int>{1, 2, 4, 8, 13, 16, 17, 41, 57, 90, 256};
         for (int n : sizes)
             for (int a : alph) {
                 Bytes d((size_t)n);

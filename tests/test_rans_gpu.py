@@ -87,6 +87,43 @@ def test_decoder_accepts_oracle_streams(engine, orc):
         assert engine.uncompress_many(streams) == datas
 
 
+def test_order1_narrow_tables(engine, orc):
+    """Dense alphabets of 2..16 symbols decode through the hand-scheduled narrow path (rans_dec.hip, narrow_block):
+    both table shapes (<= 8 and 9..16 symbols), sizes around the 256-step blocks, skewed inputs whose rare symbols take
+    two renormalisation bytes, and streams cut or flipped inside the payload (no crash, no write outside the block)."""
+    rng = np.random.default_rng(77)
+    datas = []
+    for nsym in (2, 3, 5, 6, 8, 9, 12, 15, 16):
+        vals = np.sort(rng.choice(np.arange(1, 256), nsym - 1, replace=False)).astype(np.uint8) if nsym > 1 else None
+        alph = np.concatenate([[0], vals]).astype(np.uint8)
+        for n in (1023, 1024, 1028, 4099, 300001):
+            datas.append(alph[rng.integers(0, nsym, n)].tobytes())                      # uniform
+            pr = np.full(nsym, 0.002)
+            pr[0] = 1.0 - 0.002 * (nsym - 1)
+            datas.append(alph[rng.choice(nsym, n, p=pr)].tobytes())                     # one symbol, rare others
+            datas.append(alph[np.minimum(rng.geometric(0.45, n) - 1, nsym - 1)].tobytes())  # skewed
+    datas.append(np.array([33 + (i // 3) % 7 for i in range(50000)], np.uint8).tobytes())  # no byte 0 in the data
+    streams = [orc.rans(d, 1) for d in datas]
+    assert engine.uncompress_many(streams) == datas
+    outs = engine.compress_many(datas, [1] * len(datas))
+    assert outs == streams
+    # damaged payloads: the decoder must come back (an error code or garbage of the right length), never fault
+    bad = []
+    for s in streams[12:40:3]:
+        b = bytearray(s)
+        for k in range(len(b) // 2, len(b) // 2 + 40):
+            b[k] ^= 0xA5
+        bad.append(bytes(b))
+        cut = bytes(s[:len(s) * 2 // 3])
+        bad.append(cut[:1] + (len(cut) - 9).to_bytes(4, "little") + cut[5:])
+    for t in bad:
+        try:
+            out = engine.uncompress_many([t])
+            assert len(out[0]) == int.from_bytes(t[5:9], "little")
+        except RuntimeError:
+            pass
+
+
 def test_large_quality_block(engine, orc):
     from cramtools_amd import synth
     q = synth.markov_quals(1500000, 2).tobytes()
