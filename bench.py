@@ -289,15 +289,32 @@ class DecodeStep:
             w["n_blocks"], reads.n)
 
 
-def cpu_baseline(w, budget_s=15.0):
-    """The CPU oracle (C restatement of htsjdk 2.4.1 rANS, oracle/rans4x8.c) on a bounded sample of the same blocks."""
+def host_threads():
+    """Threads of the CPU legs: every core this process may use.  The GPU boxes show the whole machine in os.cpu_count()
+    but give a job a share of it, exported as OMP_NUM_THREADS (16 per GPU); elsewhere it is os.cpu_count()."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return n
+
+
+def cpu_baseline(w, budget_s=12.0):
+    """The CPU oracle (C restatement of htsjdk 2.4.1 rANS, oracle/rans4x8.c) on a bounded sample of the same blocks:
+    encode (orc_rans_compress_many) and decode (orc_rans_uncompress_many) of the same containers, one call per thread
+    (one workspace of tables per thread), containers dealt round-robin to the threads."""
+    import shutil
     from oracle import orc
     orc.build()
     L = orc.lib()
-    cores = min(16, os.cpu_count() or 1)
+    cores = host_threads()
     n_series = len(SERIES)
     blocks, d_in = w["blocks"], w["d_in"]
-    # pilot on one container to size the sample
+
     def take(c0, c1):
         lo = blocks[c0 * n_series].in_off
         last = blocks[c1 * n_series - 1]
@@ -308,44 +325,67 @@ def cpu_baseline(w, budget_s=15.0):
         od = np.array([blocks[i].order for i in range(c0 * n_series, c1 * n_series)], np.int32)
         return arena, off, ln, od
 
-    def run(arena, off, ln, od, threads):
-        caps = np.array([orc.rans_bound(int(x)) for x in ln], np.int64)
-        ooff = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.int64)
-        out = np.empty(int(caps.sum()) + 16, np.uint8)
-        olen = np.zeros(ln.size, np.int32)
-        idx = [np.arange(t, ln.size // n_series, threads) for t in range(threads)]  # containers round-robin
-        def work(cs):
-            for c in cs:
-                s = slice(c * n_series, (c + 1) * n_series)
-                o, l2, d2, oo = (np.ascontiguousarray(off[s]), np.ascontiguousarray(ln[s]), np.ascontiguousarray(od[s]),
-                                 np.ascontiguousarray(ooff[s]))
-                ol = np.zeros(n_series, np.int32)
-                r = L.orc_rans_compress_many(arena.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p),
-                                             l2.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p), C.c_int32(n_series),
-                                             out.ctypes.data_as(C.c_void_p), oo.ctypes.data_as(C.c_void_p),
-                                             ol.ctypes.data_as(C.c_void_p))
-                assert r >= 0
-                olen[s] = ol
-        ths = [threading.Thread(target=work, args=(i,)) for i in idx]
+    def p(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def threaded(fn, shares):
+        ths = [threading.Thread(target=fn, args=(sh,)) for sh in shares if sh.size]
         t0 = time.perf_counter()
         for t in ths:
             t.start()
         for t in ths:
             t.join()
-        return time.perf_counter() - t0, out, ooff, olen
+        return time.perf_counter() - t0
+
+    def run(arena, off, ln, od, threads):
+        caps = np.array([orc.rans_bound(int(x)) for x in ln], np.int64)
+        ooff = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.int64)
+        out = np.empty(int(caps.sum()) + 16, np.uint8)
+        olen = np.zeros(ln.size, np.int32)
+        n_c = ln.size // n_series
+        shares = [(np.arange(t, n_c, threads)[:, None] * n_series + np.arange(n_series)[None, :]).reshape(-1)
+                  for t in range(threads)]  # block indices of thread t: containers t, t + threads, ...
+
+        def enc(idx):
+            ol = np.zeros(idx.size, np.int32)
+            r = L.orc_rans_compress_many(p(arena), p(np.ascontiguousarray(off[idx])), p(np.ascontiguousarray(ln[idx])),
+                                         p(np.ascontiguousarray(od[idx])), C.c_int32(idx.size), p(out),
+                                         p(np.ascontiguousarray(ooff[idx])), p(ol))
+            assert r >= 0
+            olen[idx] = ol
+        dt_enc = threaded(enc, shares)
+        # decode leg: the streams just made, back into a second arena laid out like the raw one
+        back = np.empty(arena.size + 16, np.uint8)
+        blen = np.zeros(ln.size, np.int32)
+
+        def dec(idx):
+            bl = np.zeros(idx.size, np.int32)
+            r = L.orc_rans_uncompress_many(p(out), p(np.ascontiguousarray(ooff[idx])), p(np.ascontiguousarray(olen[idx])),
+                                           C.c_int32(idx.size), p(back), p(np.ascontiguousarray(off[idx])),
+                                           p(np.ascontiguousarray(ln[idx])), p(bl))
+            assert r >= 0
+            blen[idx] = bl
+        dt_dec = threaded(dec, shares)
+        assert np.array_equal(blen, ln)
+        for i in range(ln.size):
+            assert np.array_equal(back[off[i]:off[i] + ln[i]], arena[off[i]:off[i] + ln[i]]), "oracle round trip, block %d" % i
+        return dt_enc, dt_dec, out, ooff, olen
 
     a, o, l, d = take(0, 1)
-    t1, _, _, _ = run(a, o, l, d, 1)
-    per_cont = max(t1, 1e-4)
+    t1, t1d, _, _, _ = run(a, o, l, d, 1)  # pilot on one container to size the sample
+    per_cont = max(t1 + t1d, 1e-4)
     n_c = int(min(w["n_cont"], max(cores, budget_s * cores / per_cont)))
     n_c = max(cores, n_c - n_c % cores) if w["n_cont"] >= cores else w["n_cont"]
     n_c = min(n_c, w["n_cont"])
     a, o, l, d = take(0, n_c)
-    dt, out, ooff, olen = run(a, o, l, d, min(cores, n_c))
+    dt, dt_dec, out, ooff, olen = run(a, o, l, d, min(cores, n_c))
     mb = float(l.sum()) / 1e6
-    return dict(value=mb / dt, unit="MB/s", cores=min(cores, n_c), kind="port",
-                sample="oracle/rans4x8.c (C restatement of htsjdk 2.4.1 RANS, not the JVM) on the first %d containers "
-                       "(%d blocks, %.1f MB raw), one container per thread at a time" % (n_c, l.size, mb)), (out, ooff, olen, n_c)
+    return dict(value=mb / dt, unit="MB/s", cores=min(cores, n_c), nproc=os.cpu_count(), kind="port",
+                jvm=shutil.which("java") is not None, decode_value=mb / dt_dec, encode_s=dt, decode_s=dt_dec,
+                sample="oracle/rans4x8.c (C restatement of htsjdk 2.4.1 RANS; no JVM on this host when jvm is false) on the "
+                       "first %d containers (%d blocks, %.1f MB raw): encode, then decode of the same streams; one call and "
+                       "one table workspace per thread, containers dealt round-robin to %d threads (all the cores this "
+                       "process is given)" % (n_c, l.size, mb, min(cores, n_c))), (out, ooff, olen, n_c)
 
 
 def pcie_inclusive(eng, w, per_job=256, n_cont=None, outstanding=4, reps=2, packed=True):
@@ -433,7 +473,40 @@ def pmc_traffic(a):
     return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
 
 
-def main():
+class GpuBackend:
+    """What main() needs from the device side: the real thing on one MI355X.  tests/test_bench_ranks.py passes a CPU
+    stand-in with the same methods to run main()'s rank logic under gloo."""
+    dist_backend = "nccl"
+
+    def __init__(self, local):
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+        torch.cuda.set_device(local)
+        self.dev = "cuda:%d" % local
+        self.eng = xc.Engine(local)
+
+    def workload(self, a, seed_shift):
+        return build_workload(self.dev, a.reads, a.ref_len, a.read_len, seed_shift,
+                              lambda reads, ref: gpu_insert_bases(self.eng, reads, ref, a.reads))
+
+    def step(self, w):
+        return Step(self.dev, self.eng, w)
+
+    def decode_step(self, w, step):
+        return DecodeStep(self.dev, self.eng, w, step)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def pcie(self, w):
+        return pcie_inclusive(self.eng, w)
+
+    def close(self):
+        self.eng.close()
+
+
+def main(argv=None, backend_factory=GpuBackend):
+    """Returns the JSON line's dict on rank 0 (None elsewhere) after printing it."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -444,37 +517,34 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-pcie", action="store_true")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
-    torch.cuda.set_device(local)
-    dev = "cuda:%d" % local
-    eng = xc.Engine(local)
+        if not dist.is_initialized():
+            dist.init_process_group(backend_factory.dist_backend)
+    be = backend_factory(local)
 
-    w = build_workload(dev, a.reads, a.ref_len, a.read_len, 10 * rank,
-                       lambda reads, ref: gpu_insert_bases(eng, reads, ref, a.reads))
-    step = Step(dev, eng, w)
+    # every rank codes its own containers (seed shifted by rank): weak scaling, no collective on the data path
+    w = be.workload(a, 10 * rank)
+    step = be.step(w)
     for _ in range(a.warmup):
         step.run(False)
     # barrier + synchronize on both sides of exactly `steps` steps, MAX over ranks (cramtools_amd/sharding.py)
-    dt = sharding.timed_region(lambda: step.run(True), a.steps, dist=dist if world > 1 else None,
-                               sync=torch.cuda.synchronize)
+    dt = sharding.timed_region(lambda: step.run(True), a.steps, dist=dist, sync=be.sync)
 
-    # decode leg (configs[2]) on rank 0, outside the timed region of the headline metric
-    dec, dec_parity = None, None
-    if rank == 0 and not a.no_decode and world == 1:
-        dec = DecodeStep(dev, eng, w, step)
+    # decode leg (configs[2]) on every rank, outside the timed region of the headline metric, timed the same way
+    dec, dec_parity, dt_dec = None, None, None
+    if not a.no_decode:
+        dec = be.decode_step(w, step)
         dec.prepare()
-        for _ in range(1 + a.steps):
-            dec.run()
-        dec.k2_ms, dec.ms = dec.k2_ms[1:], dec.ms[1:]
+        dec.run()
+        dec.k2_ms, dec.ms = [], []
+        dt_dec = sharding.timed_region(dec.run, a.steps, dist=dist, sync=be.sync)
         dec_parity = dec.verify()
 
     # parity verdict on this rank's blocks: no negative lengths, and the sampled containers equal the CPU oracle
@@ -482,6 +552,7 @@ def main():
     assert (lens >= 0).all(), "a block failed to encode: %r" % (lens[lens < 0][:8],)
     comp_bytes = int(lens[lens > 0].sum())
     extra = {}
+    line = None
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:  # the CPU leg and its block-by-block parity run at N = 1 only
             base, (out, ooff, olen, n_c) = cpu_baseline(w)
@@ -500,15 +571,16 @@ def main():
                                  traffic=pmc_traffic(a), kernel="rans_encode_kernel", ms_per_launch=enc_s * 1e3,
                                  algorithmic_bytes=algo)
         if dec is not None:
-            k2_s, dec_s = float(np.mean(dec.k2_ms)) / 1e3, float(np.mean(dec.ms)) / 1e3
+            k2_s, dec_s = float(np.mean(dec.k2_ms)) / 1e3, dt_dec / a.steps
             extra["decode"] = dict(workload="configs[2]: rANS decode of the same %d blocks + restoreReadBases / "
-                                            "restoreQualityScores of the %d reads (timed outside the K steps)" % (w["n_blocks"], a.reads),
-                                   value=w["raw_bytes"] / dec_s / 1e6, unit="MB/s", reads_per_s=a.reads / dec_s,
+                                            "restoreQualityScores of the %d reads per rank (timed outside the K steps, barrier "
+                                            "and MAX over ranks like them)" % (w["n_blocks"], a.reads),
+                                   value=w["raw_bytes"] * world / dec_s / 1e6, unit="MB/s", reads_per_s=a.reads * world / dec_s,
                                    ms_per_step=dec_s * 1e3, rans_decode_kernel_ms=k2_s * 1e3,
                                    rans_decode_GBps=algo / k2_s / 1e9, rans_decode_frac_of_hbm=algo / k2_s / 1e9 / HBM_PEAK_GBS,
                                    parity=dec_parity)
         if not a.no_pcie and world == 1:
-            extra["pcie_inclusive"] = pcie_inclusive(eng, w)
+            extra["pcie_inclusive"] = be.pcie(w)
         total_raw = w["raw_bytes"] * world
         line = dict(metric="CRAM encode hot path: uncompressed external-block payload MB/s (rANS o0/o1 + feature extraction)",
                     value=total_raw * a.steps / dt / 1e6, unit="MB/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
@@ -519,10 +591,11 @@ def main():
                                 parallelism="containers sharded by index, %d rank(s), no collective" % world),
                     reads_per_s=a.reads * world * a.steps / dt, compression_ratio=w["raw_bytes"] / max(comp_bytes, 1))
         line.update(extra)
-        print(json.dumps(line))
-    eng.close()
+        print(json.dumps(line), flush=True)
+    be.close()
     if world > 1:
         dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":

@@ -55,6 +55,7 @@ def lib():
         _LIB.orc_rans_uncompress.restype = ctypes.c_int32
         _LIB.orc_rans_raw_size.restype = ctypes.c_int32
         _LIB.orc_rans_compress_many.restype = ctypes.c_int64
+        _LIB.orc_rans_uncompress_many.restype = ctypes.c_int64
         _LIB.orc_extract_features.restype = ctypes.c_int64
         _LIB.orc_merge_quality_features.restype = ctypes.c_int64
         _LIB.orc_lossy_quals.restype = ctypes.c_int32

@@ -292,19 +292,42 @@ static uint32_t get_le32(const uint8_t* p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
+/* Per-thread workspace of the multi-block drivers: the order-1 tables (0.75 MB) and the staging buffer are allocated
+ * once per thread, not once per block (bench.py cpu_baseline). */
+typedef struct {
+    int (*F)[256];
+    enc_sym_t (*syms)[256];
+    uint8_t* scratch;
+    int64_t scratch_cap;
+    void* D[256]; /* dec_tab_t*, kept across blocks */
+} orc_ws;
+
+static void ws_free(orc_ws* ws) {
+    free(ws->F);
+    free(ws->syms);
+    free(ws->scratch);
+    for (int k = 0; k < 256; k++) free(ws->D[k]);
+    memset(ws, 0, sizeof(*ws));
+}
+
 /*
  * RANS#compress L60-73.  Returns the number of bytes written to out (0 for n == 0),
  * or a negative ORC_E_* code.  out must hold orc_rans_bound(n) bytes; a payload that
  * would overflow it (Java: BufferOverflowException) gives ORC_E_INSUFFICIENT.
  */
-int32_t orc_rans_compress(const uint8_t* in, int32_t n, int32_t order, uint8_t* out, int32_t cap) {
+static int32_t rans_compress_ws(orc_ws* ws, const uint8_t* in, int32_t n, int32_t order, uint8_t* out, int32_t cap) {
     if (order != 0 && order != 1) return ORC_E_ORDER;
     if (n == 0) return 0;
     if (n < 4) order = 0;
     int32_t bound = orc_rans_bound(n);
     /* worst case the encoder can physically emit: 2 bytes/symbol + tables + states */
     int64_t scratch_sz = (int64_t)n * 2 + 257 * 257 * 3 + 64;
-    uint8_t* scratch = (uint8_t*)malloc((size_t)scratch_sz);
+    if (ws->scratch_cap < scratch_sz) {
+        free(ws->scratch);
+        ws->scratch = (uint8_t*)malloc((size_t)scratch_sz);
+        ws->scratch_cap = ws->scratch ? scratch_sz : 0;
+    }
+    uint8_t* scratch = ws->scratch;
     if (!scratch) return ORC_E_INSUFFICIENT;
     int64_t tab_len, pay_len;
     if (order == 0) {
@@ -321,8 +344,11 @@ int32_t orc_rans_compress(const uint8_t* in, int32_t n, int32_t order, uint8_t* 
         tab_len = write_freq_row(scratch + 9, F);
         pay_len = e04(in, n, syms, scratch + 9 + tab_len);
     } else {
-        int(*F)[256] = (int(*)[256])malloc(256 * 256 * sizeof(int));
-        enc_sym_t(*syms)[256] = (enc_sym_t(*)[256])malloc(256 * 256 * sizeof(enc_sym_t));
+        if (!ws->F) ws->F = (int(*)[256])malloc(256 * 256 * sizeof(int));
+        if (!ws->syms) ws->syms = (enc_sym_t(*)[256])malloc(256 * 256 * sizeof(enc_sym_t));
+        int(*F)[256] = ws->F;
+        enc_sym_t(*syms)[256] = ws->syms;
+        if (!F || !syms) return ORC_E_INSUFFICIENT;
         int T[256];
         calc_freq_o1(in, n, F, T);
         for (int i = 0; i < 256; i++) {
@@ -336,20 +362,22 @@ int32_t orc_rans_compress(const uint8_t* in, int32_t n, int32_t order, uint8_t* 
         }
         tab_len = write_freq_o1(scratch + 9, F);
         pay_len = e14(in, n, syms, scratch + 9 + tab_len);
-        free(F);
-        free(syms);
     }
     int64_t total = 9 + tab_len + pay_len;
-    if (total > bound || total > cap) {
-        free(scratch);
-        return ORC_E_INSUFFICIENT;
-    }
+    if (total > bound || total > cap) return ORC_E_INSUFFICIENT;
     scratch[0] = (uint8_t)order;
     put_le32(scratch + 1, (uint32_t)(tab_len + pay_len));
     put_le32(scratch + 5, (uint32_t)n);
     memcpy(out, scratch, (size_t)total);
-    free(scratch);
     return (int32_t)total;
+}
+
+int32_t orc_rans_compress(const uint8_t* in, int32_t n, int32_t order, uint8_t* out, int32_t cap) {
+    orc_ws ws;
+    memset(&ws, 0, sizeof(ws));
+    int32_t r = rans_compress_ws(&ws, in, n, order, out, cap);
+    ws_free(&ws);
+    return r;
 }
 
 /* ---- decode ---- */
@@ -486,7 +514,7 @@ int32_t orc_rans_raw_size(const uint8_t* in, int32_t n) {
 }
 
 /* RANS#uncompress L29-56. Returns raw size, or negative ORC_E_*. */
-int32_t orc_rans_uncompress(const uint8_t* in, int32_t n, uint8_t* out, int32_t cap) {
+static int32_t rans_uncompress_ws(orc_ws* ws, const uint8_t* in, int32_t n, uint8_t* out, int32_t cap) {
     if (n == 0) return 0;
     if (n < 9) return ORC_E_INPUT_LENGTH;
     int order = in[0];
@@ -500,22 +528,25 @@ int32_t orc_rans_uncompress(const uint8_t* in, int32_t n, uint8_t* out, int32_t 
     int64_t p = 9, end = n;
     int rc;
     if (order == 0) {
-        dec_tab_t* D = (dec_tab_t*)calloc(1, sizeof(dec_tab_t));
-        if (read_freq_row(in, &p, end, D, 0) != 0) {
-            free(D);
-            return ORC_E_CORRUPT;
-        }
+        if (!ws->D[0]) ws->D[0] = calloc(1, sizeof(dec_tab_t));
+        dec_tab_t* D = (dec_tab_t*)ws->D[0];
+        memset(D, 0, sizeof(*D));
+        if (read_freq_row(in, &p, end, D, 0) != 0) return ORC_E_CORRUPT;
         rc = d04(in, p, end, D, out, raw);
-        free(D);
     } else {
-        dec_tab_t** D = (dec_tab_t**)calloc(256, sizeof(dec_tab_t*));
+        dec_tab_t* D[256]; /* the contexts this block defines (a workspace table is cleared when a block takes it) */
+        memset(D, 0, sizeof(D));
         rc = 0;
         /* Frequencies#readStats_o1 L50-106 */
         int rle_i = 0;
         if (p >= end) rc = ORC_E_CORRUPT;
         int i = rc ? 0 : in[p++];
         if (!rc) do {
-                if (!D[i]) D[i] = (dec_tab_t*)calloc(1, sizeof(dec_tab_t));
+                if (!D[i]) {
+                    if (!ws->D[i]) ws->D[i] = calloc(1, sizeof(dec_tab_t));
+                    D[i] = (dec_tab_t*)ws->D[i];
+                    memset(D[i], 0, sizeof(dec_tab_t));
+                }
                 if (read_freq_row(in, &p, end, D[i], 1) != 0 || p >= end) {
                     rc = ORC_E_CORRUPT;
                     break;
@@ -539,22 +570,52 @@ int32_t orc_rans_uncompress(const uint8_t* in, int32_t n, uint8_t* out, int32_t 
                 }
             } while (i != 0);
         if (!rc) rc = d14(in, p, end, D, out, raw);
-        for (int k = 0; k < 256; k++) free(D[k]);
-        free(D);
     }
     return rc ? rc : raw;
 }
 
-/* Multi-block driver used by bench.py's cpu_baseline leg (1 thread per call). */
+int32_t orc_rans_uncompress(const uint8_t* in, int32_t n, uint8_t* out, int32_t cap) {
+    orc_ws ws;
+    memset(&ws, 0, sizeof(ws));
+    int32_t r = rans_uncompress_ws(&ws, in, n, out, cap);
+    ws_free(&ws);
+    return r;
+}
+
+/* Multi-block drivers of bench.py's cpu_baseline legs: one call = one thread's share of the blocks, one workspace. */
 int64_t orc_rans_compress_many(const uint8_t* in, const int64_t* in_off, const int32_t* in_len, const int32_t* order,
                                int32_t nblocks, uint8_t* out, const int64_t* out_off, int32_t* out_len) {
+    orc_ws ws;
+    memset(&ws, 0, sizeof(ws));
     int64_t total = 0;
     for (int b = 0; b < nblocks; b++) {
         int32_t cap = orc_rans_bound(in_len[b]);
-        int32_t r = orc_rans_compress(in + in_off[b], in_len[b], order[b], out + out_off[b], cap);
+        int32_t r = rans_compress_ws(&ws, in + in_off[b], in_len[b], order[b], out + out_off[b], cap);
         out_len[b] = r;
-        if (r < 0) return r;
+        if (r < 0) {
+            total = r;
+            break;
+        }
         total += r;
     }
+    ws_free(&ws);
+    return total;
+}
+
+int64_t orc_rans_uncompress_many(const uint8_t* in, const int64_t* in_off, const int32_t* in_len, int32_t nblocks, uint8_t* out,
+                                 const int64_t* out_off, const int32_t* out_cap, int32_t* out_len) {
+    orc_ws ws;
+    memset(&ws, 0, sizeof(ws));
+    int64_t total = 0;
+    for (int b = 0; b < nblocks; b++) {
+        int32_t r = rans_uncompress_ws(&ws, in + in_off[b], in_len[b], out + out_off[b], out_cap[b]);
+        out_len[b] = r;
+        if (r < 0) {
+            total = r;
+            break;
+        }
+        total += r;
+    }
+    ws_free(&ws);
     return total;
 }

@@ -12,7 +12,7 @@ rows = list(cur.execute("select name, count(*), sum(duration), avg(duration), mi
                         "max(workgroup_x), max(vgpr_count), max(lds_size) from kernels group by name order by sum(duration) desc"))
 tot = sum(r[2] for r in rows)
 with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (durations in ns; "
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie (durations in ns; "
             "includes the untimed workload set-up kernels of torch)\n")
     f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage,Grid,Workgroup,ArchVGPR,LDS\n")
     for r in rows[:40]:
@@ -26,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     with open(os.path.join(out, "%s_pmc_%s.csv" % (tag, c)), "w") as f:
         f.write("# rocprofv3 --pmc %s --kernel-include-regex 'rans_encode|rans_decode|extract_|gather_copy|restore_' -- python3 bench.py --steps 1 "
-                "--warmup 1 --no-cpu-baseline ; counter unit KB per dispatch (raw, uncorrected)\n" % c)
+                "--warmup 1 --no-cpu-baseline --no-pcie ; counter unit KB per dispatch (raw, uncorrected)\n" % c)
         f.write("Kernel,Dispatches,MeanKB,MinKB,MaxKB\n")
         for k, v in agg.items():
             f.write('"%s",%d,%.0f,%.0f,%.0f\n' % (k[:110], len(v), sum(v) / len(v), min(v), max(v)))

@@ -7,7 +7,7 @@ TAG=${1:-sq}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_$TAG
-timeout -s KILL 420 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU --kernel-include-regex "rans_encode|rans_decode" -d $R/gpurun_out/pmc_$TAG -o pmc --output-format csv -- python3 -u $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_$TAG.log 2>&1 || { echo "pmc $TAG failed"; tail -20 $R/gpurun_out/pmc_$TAG.log; exit 1; }
+timeout -s KILL 420 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU --kernel-include-regex "rans_encode|rans_decode" -d $R/gpurun_out/pmc_$TAG -o pmc --output-format csv -- python3 -u $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pcie > $R/gpurun_out/pmc_$TAG.log 2>&1 || { echo "pmc $TAG failed"; tail -20 $R/gpurun_out/pmc_$TAG.log; exit 1; }
 python3 - $R/gpurun_out/pmc_$TAG <<'PY'
 import collections, csv, glob, sys
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
