@@ -920,6 +920,24 @@ int64_t cramgpu_extract_features_dev(cramgpu_ctx* c, const cramgpu_reads* reads,
     return total;
 }
 
+int32_t cramgpu_write_series_dev(cramgpu_ctx* c, const cramgpu_reads* reads, const cramgpu_record_cols* cols,
+                                 const cramgpu_features* feats, uint8_t* d_arena, int64_t arena_cap, int64_t* d_series_off,
+                                 int32_t* d_series_len, int32_t* d_status, void* stream) {
+    if (!c || !reads || !cols || !feats || !d_arena || !d_series_off || !d_series_len || !d_status || reads->n_reads < 0 ||
+        reads->n_cont < 1 || arena_cap < 16)
+        return fail(CRAMGPU_E_ARG, "write_series: bad argument");
+    if (!cols->bam_flags || !cols->comp_flags || !cols->read_group || !cols->mate_flags || !cols->mate_ref || !cols->mate_start ||
+        !cols->tlen || !cols->next_frag || !cols->tag_list || (cols->cont_multiref && !cols->ref_id) || !reads->mapq ||
+        !reads->quals || !feats->off || (reads->n_cont > 1 && !reads->read_cont))
+        return fail(CRAMGPU_E_ARG, "write_series: a column is missing");
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(launch_write_series(*reads, *cols, *feats, d_arena, arena_cap, d_series_off, d_series_len, d_status, s));
+    return 0;
+}
+
 int32_t cramgpu_assign_codes_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_cont, int32_t n_cont,
                                  const cramgpu_features* feats, const uint8_t* matrices, void* stream) {
     if (!c || !feats || !matrices || n_reads < 0 || n_cont < 1) return fail(CRAMGPU_E_ARG, "assign_codes: bad argument");

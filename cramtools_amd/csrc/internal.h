@@ -57,6 +57,8 @@ hipError_t launch_gather(const uint8_t* src, const int64_t* pos, const int32_t* 
                          hipStream_t s);
 
 // record kernels
+hipError_t launch_write_series(const cramgpu_reads& r, const cramgpu_record_cols& c, const cramgpu_features& f, uint8_t* arena,
+                               int64_t cap, int64_t* d_off, int32_t* d_len, int32_t* d_status, hipStream_t s);
 void records_set_cu_count(int n_cu);  // grid sizing of the record kernels
 hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
                                    int32_t* d_counts, bool write_pass, int32_t* list, uint32_t* list_n,

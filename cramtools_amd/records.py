@@ -146,6 +146,68 @@ class FeatureBatch:
                     b=self.b[:n].cpu().numpy(), off=self.off.cpu().numpy())
 
 
+RECORD_COLS = ("bam_flags", "comp_flags", "ref_id", "read_group", "mate_flags", "mate_ref", "mate_start", "tlen", "next_frag",
+               "tag_list")
+
+
+class RecordColumns:
+    """The CramCompressionRecord fields that reads and features do not hold, as device int32 arrays
+    (cramgpu_record_cols): what htsjdk!encoding/writer/Writer#write reads besides bases, scores and features."""
+
+    def __init__(self, device, n_reads, multiref=None, ap_base=None, ap_delta=True, **cols):
+        torch = _torch()
+        self.device, self.n = device, n_reads
+        for k in RECORD_COLS:
+            v = cols.get(k)
+            setattr(self, k, _dev(v, torch.int32, device) if v is not None else torch.zeros(n_reads, dtype=torch.int32, device=device))
+        self.multiref = _dev(multiref, torch.uint8, device) if multiref is not None else None
+        self.ap_base = _dev(ap_base, torch.int32, device) if ap_base is not None else None
+        self.ap_delta = bool(ap_delta)
+
+    def struct(self):
+        c = _lib.RecordCols()
+        for k in RECORD_COLS:
+            setattr(c, k, getattr(self, k).data_ptr())
+        c.cont_multiref = self.multiref.data_ptr() if self.multiref is not None else None
+        c.cont_ap_base = self.ap_base.data_ptr() if self.ap_base is not None else None
+        c.ap_delta = 1 if self.ap_delta else 0
+        return c
+
+
+class Writer:
+    """htsjdk!encoding/writer/Writer (L139-261) over whole containers: every record's values appended to its slice's
+    data series, one byte stream per content id (cramgpu_write_series_dev).  The streams of the batch lie in `arena`
+    (device), 16-byte aligned, at off[c, id] with length len[c, id]: the input arena of the rANS encoder as it is."""
+
+    def __init__(self, engine, device, n_cont, arena_bytes):
+        torch = _torch()
+        self.engine, self.device, self.n_cont = engine, device, n_cont
+        self.arena = torch.zeros(int(arena_bytes) + 16, dtype=torch.uint8, device=device)
+        self.off = torch.zeros(n_cont * _lib.N_SERIES, dtype=torch.int64, device=device)
+        self.len = torch.zeros(n_cont * _lib.N_SERIES, dtype=torch.int32, device=device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def write(self, reads, cols, feats):
+        """Stream-ordered; lengths() synchronises."""
+        rs, cs, fs = reads.struct(), cols.struct(), feats.struct()
+        _lib.check(_lib.lib().cramgpu_write_series_dev(self.engine.handle, C.byref(rs), C.byref(cs), C.byref(fs),
+                                                       self.arena.data_ptr(), int(self.arena.numel()), self.off.data_ptr(),
+                                                       self.len.data_ptr(), self.status.data_ptr(), _stream()))
+
+    def lengths(self):
+        """(off[n_cont, 30], len[n_cont, 30]) on the host; raises what the device reported."""
+        st = int(self.status.item())
+        if st != 0:
+            raise _lib.CramGpuError(st, "data-series writer")
+        return (self.off.cpu().numpy().reshape(self.n_cont, _lib.N_SERIES), self.len.cpu().numpy().reshape(self.n_cont, _lib.N_SERIES))
+
+    def series(self, c, name_or_id):
+        """bytes of one stream (tests)."""
+        k = _lib.SERIES_ID[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+        off, ln = self.lengths()
+        return self.arena[int(off[c, k]):int(off[c, k]) + int(ln[c, k])].cpu().numpy().tobytes()
+
+
 def substitution_matrix(hist25):
     """SubstitutionMatrix#<init>([[J): 25 counts ([ref][base] over ACGTN) -> 5 header bytes."""
     h = np.ascontiguousarray(hist25, np.int64).reshape(-1)

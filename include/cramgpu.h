@@ -280,6 +280,64 @@ int32_t cramgpu_restore_quals_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32
                                   const cramgpu_features* feats, uint8_t default_qs, uint8_t* d_scores,
                                   const int64_t* d_out_off, int32_t* d_status, void* stream);
 
+/* =====================================================================================================
+ * Data series — htsjdk!encoding/writer/Writer#write (L139-261) and htsjdk!encoding/reader/CramRecordReader#read (L59-211)
+ * over flat records, htsjdk!io/ITF8#writeUnsignedITF8 (L53-84) / #readUnsignedITF8.  Call sites in the reference:
+ * htsjdk!build/ContainerFactory#buildSlice L129-205 (from src/main/java/htsjdk/samtools/cram/CramSerilization.java:182)
+ * and htsjdk!build/ContainerParser#getRecords (from src/main/java/net/sf/cram/Cram2Bam.java:209); the same field
+ * order is spelled out in source by the reference's own readers,
+ * src/main/java/htsjdk/samtools/cram/encoding/reader/ReaderToBAM.java:64-176 and ReadFeatureBuffer.java:41-100.
+ * A series is addressed by its content id = htsjdk EncodingKey ordinal.  Integer series are ITF8, FC / BS / BA / QS are
+ * bytes, IN / SC are byte arrays closed by '\t' (ByteArrayStopEncoding).  Read names and tag values (RN, TN, TC and
+ * the per-tag series) are strings the host keeps: their slots stay empty.
+ * ===================================================================================================== */
+#define CRAMGPU_N_SERIES 30
+enum {
+    CRAMGPU_DS_BF = 0, CRAMGPU_DS_AP = 1, CRAMGPU_DS_FP = 2, CRAMGPU_DS_FC = 3, CRAMGPU_DS_QS = 4, CRAMGPU_DS_DL = 5,
+    CRAMGPU_DS_BA = 6, CRAMGPU_DS_TN = 7, CRAMGPU_DS_NF = 8, CRAMGPU_DS_RL = 9, CRAMGPU_DS_RG = 10, CRAMGPU_DS_MQ = 11,
+    CRAMGPU_DS_RN = 12, CRAMGPU_DS_NP = 13, CRAMGPU_DS_TS = 14, CRAMGPU_DS_FN = 15, CRAMGPU_DS_BS = 16, CRAMGPU_DS_IN = 17,
+    CRAMGPU_DS_TC = 18, CRAMGPU_DS_MF = 19, CRAMGPU_DS_NS = 20, CRAMGPU_DS_CF = 21, CRAMGPU_DS_TV = 22, CRAMGPU_DS_TM = 23,
+    CRAMGPU_DS_TL = 24, CRAMGPU_DS_RI = 25, CRAMGPU_DS_RS = 26, CRAMGPU_DS_SC = 27, CRAMGPU_DS_HC = 28, CRAMGPU_DS_PD = 29
+};
+/* CramCompressionRecord compression-flag bits and the BAM flag the writer branches on */
+#define CRAMGPU_CF_FORCE_PRESERVE_QS 1
+#define CRAMGPU_CF_DETACHED 2
+#define CRAMGPU_CF_HAS_MATE_DOWNSTREAM 4
+#define CRAMGPU_CF_UNKNOWN_BASES 8
+#define CRAMGPU_BF_SEGMENT_UNMAPPED 4
+
+/* The fields of CramCompressionRecord that cramgpu_reads / cramgpu_features do not hold (device arrays, [n_reads]).
+ * The writer reads them, the reader fills them (columns a record does not carry are set to 0). */
+typedef struct {
+    int32_t* bam_flags;   /* BF */
+    int32_t* comp_flags;  /* CF */
+    int32_t* ref_id;      /* RI: written / read for containers with cont_multiref[c] != 0 */
+    int32_t* read_group;  /* RG */
+    int32_t* mate_flags;  /* MF (detached records) */
+    int32_t* mate_ref;    /* NS */
+    int32_t* mate_start;  /* NP */
+    int32_t* tlen;        /* TS */
+    int32_t* next_frag;   /* NF (records with a mate downstream) */
+    int32_t* tag_list;    /* TL */
+    const uint8_t* cont_multiref; /* [n_cont] slice sequence id is MULTI_REFERENCE, or NULL = none */
+    const int32_t* cont_ap_base;  /* [n_cont] slice alignment start the first AP delta is taken from, or NULL = the
+                                     first record's own start (delta 0) */
+    int32_t ap_delta;             /* CompressionHeader.AP_seriesDelta */
+    int32_t reserved;
+} cramgpu_record_cols;
+
+/* Writer#write for every record of every container of the batch.  Needs reads->bases, quals, base_off, read_len,
+ * aln_start, mapq, read_cont and the feature columns after code assignment (X: a >> 16 = code).  The streams of
+ * container c are laid into d_arena one after the other in content-id order, each on a 16-byte boundary (the layout the
+ * rANS encoder wants: cramgpu_block.in_off / in_len can be taken straight from the two tables):
+ *   d_series_off[c * CRAMGPU_N_SERIES + id], d_series_len[...]   (device)
+ * d_status[0] = 0, or CRAMGPU_E_INSUFFICIENT when the streams need more than arena_cap bytes (nothing is written then;
+ * d_series_len still holds the lengths), or CRAMGPU_E_ARG for an unknown operator byte.
+ * Stream-ordered, does not synchronise, allocates nothing. */
+int32_t cramgpu_write_series_dev(cramgpu_ctx* ctx, const cramgpu_reads* reads, const cramgpu_record_cols* cols,
+                                 const cramgpu_features* feats, uint8_t* d_arena, int64_t arena_cap, int64_t* d_series_off,
+                                 int32_t* d_series_len, int32_t* d_status, void* stream);
+
 /* Q1 result — htsjdk!lossy/PreservationPolicy as a POD (parsed on the host by the caller, see
  * src/main/java/htsjdk/samtools/cram/lossy/QualityScorePreservation.java:167-256). */
 typedef struct {

@@ -37,7 +37,7 @@ class Policy(ctypes.Structure):
 def build():
     """Compile liboracle.so with gcc (idempotent)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rans4x8.c", "records.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("rans4x8.c", "records.c", "series.c")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
     return so
@@ -60,6 +60,8 @@ def lib():
         _LIB.orc_merge_quality_features.restype = ctypes.c_int64
         _LIB.orc_lossy_quals.restype = ctypes.c_int32
         _LIB.orc_tracks_windows.restype = ctypes.c_int32
+        _LIB.orc_write_series.restype = ctypes.c_int32
+        _LIB.orc_read_series.restype = ctypes.c_int64
     return _LIB
 
 
@@ -363,3 +365,82 @@ def merge_quality_features(reads, scores, force, qstatus, feats):
     if n < 0:
         raise RuntimeError("merge capacity too small")
     return dict(op=m_op[:n], pos=m_pos[:n], a=m_a[:n], b=m_b[:n], off=m_off)
+
+
+# ---------------------------------------------------------------- data series (Writer#write / CramRecordReader#read)
+N_SERIES = 30
+SERIES_ID = dict(BF=0, AP=1, FP=2, FC=3, QS=4, DL=5, BA=6, TN=7, NF=8, RL=9, RG=10, MQ=11, RN=12, NP=13, TS=14, FN=15, BS=16,
+                 IN=17, TC=18, MF=19, NS=20, CF=21, TV=22, TM=23, TL=24, RI=25, RS=26, SC=27, HC=28, PD=29)
+RECORD_COLS = ("bam_flags", "comp_flags", "ref_id", "read_group", "mate_flags", "mate_ref", "mate_start", "tlen", "next_frag",
+               "tag_list")
+
+
+def itf8(values):
+    """ITF8#writeUnsignedITF8 of every value -> bytes."""
+    out = np.empty(5 * len(values) + 8, np.uint8)
+    n = 0
+    for v in values:
+        n += lib().orc_itf8_put(ctypes.c_void_p(out.ctypes.data + n), ctypes.c_int32(int(v)))
+    return out[:n].tobytes()
+
+
+def write_series(cols, read_len, aln_start, mapq, bases, quals, base_off, feats, multiref=False, ap_base=None, ap_delta=True,
+                 lo=0, hi=None):
+    """Writer#write over records [lo, hi) of a batch (one slice): cols = dict of the RECORD_COLS int32 arrays, feats = dict
+    off/op/pos/a/b.  Returns the N_SERIES byte strings (index = content id)."""
+    hi = len(read_len) if hi is None else hi
+    n = hi - lo
+    i32 = lambda a: np.ascontiguousarray(np.asarray(a)[lo:hi], np.int32)
+    c = [i32(cols[k]) for k in RECORD_COLS]
+    rl, st = i32(read_len), i32(aln_start)
+    mq = np.ascontiguousarray(np.asarray(mapq)[lo:hi], np.uint8)
+    boff = np.ascontiguousarray(np.asarray(base_off)[lo:hi], np.int64)
+    foff = np.ascontiguousarray(np.asarray(feats["off"])[lo:hi + 1], np.int64)
+    nfeat = int(foff[-1] - foff[0])
+    cap = int(5 * n * 2 + 6 * nfeat + 2 * int(rl.sum()) + 64)
+    out = np.empty(N_SERIES * cap, np.uint8)
+    out_len = np.zeros(N_SERIES, np.int64)
+    if ap_base is None:
+        ap_base = int(st[0]) if n else 0
+    bases, quals = _u8(bases), _u8(quals)
+    r = lib().orc_write_series(ctypes.c_int32(n), _p(rl), _p(st), _p(c[0]), _p(c[1]), _p(c[2]), _p(c[3]), _p(c[4]), _p(c[5]),
+                               _p(c[6]), _p(c[7]), _p(c[8]), _p(c[9]), _p(mq), _p(bases), _p(quals), _p(boff), _p(foff),
+                               _p(np.ascontiguousarray(feats["op"], np.uint8)), _p(np.ascontiguousarray(feats["pos"], np.int32)),
+                               _p(np.ascontiguousarray(feats["a"], np.int32)), _p(np.ascontiguousarray(feats["b"], np.int32)),
+                               ctypes.c_int32(1 if multiref else 0), ctypes.c_int32(ap_base), ctypes.c_int32(1 if ap_delta else 0),
+                               _p(out), ctypes.c_int64(cap), _p(out_len))
+    if r != 0:
+        raise RuntimeError("oracle write_series error %d" % r)
+    return [out[k * cap:k * cap + int(out_len[k])].tobytes() for k in range(N_SERIES)]
+
+
+def read_series(streams, n_reads, multiref=False, ap_base=0, ap_delta=True):
+    """CramRecordReader#read over the N_SERIES byte strings of one slice -> dict of columns (see oracle/series.c)."""
+    cap = max(max(len(s) for s in streams), 1)
+    arena = np.zeros(N_SERIES * cap, np.uint8)
+    in_len = np.zeros(N_SERIES, np.int64)
+    for k, s in enumerate(streams):
+        arena[k * cap:k * cap + len(s)] = np.frombuffer(s, np.uint8)
+        in_len[k] = len(s)
+    z = lambda dt, m=n_reads: np.zeros(m, dt)
+    res = {k: z(np.int32) for k in RECORD_COLS + ("read_len", "aln_start")}
+    res["mapq"] = z(np.uint8)
+    res["base_off"], res["seq_off"], res["feat_off"] = z(np.int64, n_reads + 1), z(np.int64, n_reads + 1), z(np.int64, n_reads + 1)
+    bases_cap = len(streams[SERIES_ID["QS"]]) + len(streams[SERIES_ID["BA"]]) + 5 * n_reads * 0 + sum(len(s) for s in streams) + 16
+    bases_cap = max(bases_cap, 1 << 16) * 64
+    feat_cap = len(streams[SERIES_ID["FC"]]) + 1
+    res["bases"], res["quals"] = np.zeros(bases_cap, np.uint8), np.zeros(bases_cap, np.uint8)
+    res["op"], res["pos"], res["a"], res["b"] = z(np.uint8, feat_cap), z(np.int32, feat_cap), z(np.int32, feat_cap), z(np.int32, feat_cap)
+    seq_cap = len(streams[SERIES_ID["IN"]]) + len(streams[SERIES_ID["SC"]]) + 1
+    res["seq"] = z(np.uint8, seq_cap)
+    c = [res[k] for k in RECORD_COLS]
+    r = lib().orc_read_series(ctypes.c_int32(n_reads), _p(arena), ctypes.c_int64(cap), _p(in_len), ctypes.c_int32(1 if multiref else 0),
+                              ctypes.c_int32(ap_base), ctypes.c_int32(1 if ap_delta else 0), _p(res["read_len"]), _p(res["aln_start"]),
+                              _p(c[0]), _p(c[1]), _p(c[2]), _p(c[3]), _p(c[4]), _p(c[5]), _p(c[6]), _p(c[7]), _p(c[8]), _p(c[9]),
+                              _p(res["mapq"]), _p(res["base_off"]), _p(res["bases"]), _p(res["quals"]), ctypes.c_int64(bases_cap),
+                              _p(res["feat_off"]), _p(res["op"]), _p(res["pos"]), _p(res["a"]), _p(res["b"]), ctypes.c_int64(feat_cap),
+                              _p(res["seq"]), _p(res["seq_off"]), ctypes.c_int64(seq_cap))
+    if r < 0:
+        raise RuntimeError("oracle read_series error %d" % r)
+    res["n_feat"] = int(r)
+    return res

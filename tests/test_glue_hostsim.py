@@ -149,3 +149,12 @@ def test_bench_step_on_host_build(hostsim, orc, monkeypatch):
         assert "round-trip" in dec.verify()
     finally:
         eng.close()
+
+
+def test_series_writer_test_bodies(hostsim, orc, monkeypatch):
+    """tests/test_series_gpu.py on the host build of csrc/series.hip."""
+    import test_series_gpu as t
+    monkeypatch.setattr(t, "DEV", "cpu")
+    t.test_writer_matches_oracle(orc, 0, [1])
+    t.test_writer_matches_oracle(orc, 2, [300, 5, 257])
+    t.test_writer_feeds_the_encoder(orc)

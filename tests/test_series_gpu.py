@@ -1,0 +1,132 @@
+"""The data-series writer (cramgpu_write_series_dev) against the oracle's Writer#write
+(oracle/series.c): random slices with every operator, every record kind and every ITF8 width, several containers per
+batch (multi-reference and explicit slice starts included), the capacity guard, and the series of a K3-extracted
+container feeding the rANS encoder as they lie."""
+import numpy as np
+import pytest
+
+from tests import series_cases as sc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _batch(rng, sizes):
+    """Several random slices back to back as one batch: (ReadBatch, RecordColumns kwargs, FeatureBatch, per-slice dicts)."""
+    from cramtools_amd import records
+    parts = [sc.random_slice(rng, n) for n in sizes]
+    n = sum(sizes)
+    read_len = np.concatenate([p["read_len"] for p in parts])
+    base_off = np.concatenate([[0], np.cumsum(read_len)[:-1]]).astype(np.int64)
+    bases = np.concatenate([p["bases"][:int(p["base_off"][-1])] for p in parts] + [np.zeros(16, np.uint8)])
+    quals = np.concatenate([p["quals"][:int(p["base_off"][-1])] for p in parts] + [np.zeros(16, np.uint8)])
+    aln_start = np.concatenate([p["aln_start"] for p in parts])
+    mapq = np.concatenate([p["mapq"] for p in parts])
+    read_cont = np.concatenate([np.full(s, c, np.int32) for c, s in enumerate(sizes)])
+    reads = records.ReadBatch(DEV, bases, base_off, read_len, aln_start, np.zeros(1, np.int32), np.zeros(n, np.int64),
+                              np.zeros(n, np.int32), quals=quals, mapq=mapq, read_cont=read_cont,
+                              windows=[(0, 0, 0)] * len(sizes))
+    cols = {k: np.concatenate([p["cols"][k] for p in parts]) for k in records.RECORD_COLS}
+    f_off = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(p["feats"]["off"]) for p in parts]))]).astype(np.int64)
+    cat = lambda k, dt: np.concatenate([p["feats"][k] for p in parts]).astype(dt)
+    feats = records.FeatureBatch.from_host(DEV, cat("op", np.uint8), cat("pos", np.int32), cat("a", np.int32), cat("b", np.int32), f_off)
+    return reads, cols, feats, parts
+
+
+@pytest.mark.parametrize("seed,sizes", [(0, [1]), (1, [300]), (2, [700, 5, 256, 257]), (3, [64, 1, 1000])])
+def test_writer_matches_oracle(orc, seed, sizes):
+    from cramtools_amd import external_compression as xc, records
+    rng = np.random.default_rng(100 + seed)
+    reads, cols, feats, parts = _batch(rng, sizes)
+    n_cont = len(sizes)
+    multiref = np.array([(c + seed) & 1 for c in range(n_cont)], np.uint8)
+    ap_base = np.array([int(p["aln_start"][0]) - (c % 3) for c, p in enumerate(parts)], np.int32)
+    ap_delta = seed != 3
+    eng = xc.Engine(0)
+    try:
+        rc = records.RecordColumns(DEV, reads.n, multiref=multiref, ap_base=ap_base, ap_delta=ap_delta, **cols)
+        w = records.Writer(eng, DEV, n_cont, 8 * int(reads.bases.numel()) + 70 * reads.n + 4096)
+        w.write(reads, rc, feats)
+        off, ln = w.lengths()
+        assert (off % 16 == 0).all()
+        arena = w.arena.cpu().numpy()
+        for c, p in enumerate(parts):
+            want = orc.write_series(p["cols"], p["read_len"], p["aln_start"], p["mapq"], p["bases"], p["quals"], p["base_off"],
+                                    p["feats"], multiref=bool(multiref[c]), ap_base=int(ap_base[c]), ap_delta=ap_delta)
+            for k in range(30):
+                got = arena[int(off[c, k]):int(off[c, k]) + int(ln[c, k])].tobytes()
+                assert got == want[k], (c, k, len(got), len(want[k]))
+        # the streams do not overlap and follow each other in (container, content id) order
+        flat_off, flat_len = off.reshape(-1), ln.reshape(-1)
+        assert (flat_off[1:] >= flat_off[:-1] + flat_len[:-1]).all()
+        # capacity guard: nothing is written and the device reports the reference-free code
+        small = records.Writer(eng, DEV, n_cont, 64)
+        small.arena.fill_(0xEE)
+        small.write(reads, rc, feats)
+        with pytest.raises(RuntimeError):
+            small.lengths()
+        assert np.array_equal(small.len.cpu().numpy().reshape(n_cont, 30), ln)
+        assert bool((small.arena == 0xEE).all())
+    finally:
+        eng.close()
+
+
+def test_writer_feeds_the_encoder(orc):
+    """K3 -> F3 -> writer -> K1 on one container of synthetic reads: the writer's QS / BA / FC / FP / BS streams are what
+    the oracle's writer makes of the oracle's features, and the rANS encoder takes them from the writer's arena."""
+    import torch
+    from cramtools_amd import external_compression as xc, records, synth, _lib
+    rng = np.random.default_rng(7)
+    ref = synth.reference(40000)
+    rs = synth.make_reads(3000, ref, read_len=100, sub_rate=0.01, indel_rate=0.004, softclip_frac=0.05)
+    pad = np.zeros(16, np.uint8)
+
+    class R:
+        pass
+    o_reads = R()
+    o_reads.n = rs.n
+    for k in ("base_off", "read_len", "aln_start", "rflags", "cigar_off", "n_cigar"):
+        setattr(o_reads, k, np.ascontiguousarray(getattr(rs, k)))
+    o_reads.bases, o_reads.quals = np.concatenate([rs.bases, pad]), np.concatenate([rs.quals, pad])
+    o_reads.cigar = np.concatenate([rs.cigar, np.zeros(1, np.uint32)])
+    eng = xc.Engine(0)
+    try:
+        reads = records.ReadBatch(DEV, o_reads.bases, rs.base_off, rs.read_len, rs.aln_start, o_reads.cigar.view(np.int32),
+                                  rs.cigar_off, rs.n_cigar, quals=o_reads.quals, mapq=rs.mapq, windows=((0, ref.size, 0),))
+        d_ref = torch.as_tensor(np.concatenate([ref, np.zeros(16, np.uint8)])).to(DEV)
+        fac = records.Sam2CramRecordFactory(eng)
+        fac.set_ref_bases(d_ref)
+        feats, hist = fac.create_variations(reads, feature_cap=3000 * 30)
+        m = records.substitution_matrix(hist[0])
+        fac.assign_codes(reads, feats, m)
+        want_f = orc.extract_features(o_reads, ref)
+        orc.assign_codes(want_f, orc.substitution_matrix(want_f["hist"]))
+        n = reads.n
+        cols = dict(bam_flags=rng.choice([99, 147, 83, 163], n), comp_flags=np.full(n, 3), read_group=np.full(n, -1),
+                    mate_ref=np.zeros(n), mate_start=rng.integers(1, 40000, n), tlen=rng.integers(-500, 500, n),
+                    tag_list=np.zeros(n))
+        rc = records.RecordColumns(DEV, n, **cols)
+        w = records.Writer(eng, DEV, 1, 4 * int(reads.bases.numel()) + 70 * n + 4096)
+        w.write(reads, rc, feats)
+        off, ln = w.lengths()
+        full = {k: np.asarray(cols.get(k, np.zeros(n)), np.int32) for k in records.RECORD_COLS}
+        want = orc.write_series(full, o_reads.read_len, o_reads.aln_start, rs.mapq, o_reads.bases, o_reads.quals,
+                                o_reads.base_off, want_f)
+        for name in ("QS", "BA", "FC", "FP", "BS", "FN", "AP", "TS", "NP", "IN", "SC", "DL", "MQ"):
+            assert w.series(0, name) == want[_lib.SERIES_ID[name]], name
+        # the rANS series straight from the writer's arena (descriptors from its two tables)
+        ids = [(_lib.SERIES_ID[s], o) for s, o in (("QS", 1), ("AP", 0), ("BA", 1), ("BF", 1), ("CF", 1), ("TS", 1))]
+        lens = [int(ln[0, k]) for k, _ in ids]
+        blocks, _, out_bytes = xc.Engine.plan_encode(lens, [o for _, o in ids])
+        for i, (k, _) in enumerate(ids):
+            blocks[i].in_off = int(off[0, k])
+        d_out = torch.zeros(out_bytes, dtype=torch.uint8, device=DEV)
+        d_len = torch.zeros(len(ids), dtype=torch.int32, device=DEV)
+        d_pos = torch.zeros(len(ids), dtype=torch.int64, device=DEV)
+        eng.encode_dev(w.arena, d_out, blocks, len(ids), d_len, d_pos)
+        for i, (k, o) in enumerate(ids):
+            got = d_out[int(d_pos[i]):int(d_pos[i]) + int(d_len[i])].cpu().numpy().tobytes()
+            assert got == orc.rans(want[k], o), k
+    finally:
+        eng.close()
