@@ -4,12 +4,14 @@
 One "step" = one pass of the encode hot path over the whole synthetic read set resident in HBM:
   K3  reference-diff feature extraction over every read (two passes + scan, substitution histogram),
   F3  substitution matrices + code assignment (device, per container),
+  W   data-series writer: every record's values into one byte stream per series per container (the K1 input arena),
   K1  rANS order-0 / order-1 encode of every external block of every container (QS, BA, BF, CF, NS, RG, RL, TS
       order 1; AP, RI order 0 — the fixed series->codec map of CompressionHeaderFactory#build L82-124),
   gather of the compressed streams into one dense arena (what would cross PCIe).
 Workload: 10M x 150 bp Illumina-like reads vs a 64 Mbp synthetic reference, 1000 containers of 10 000 reads,
-lossless qualities.  The external-block byte streams are synthesised on the device once (untimed): the data-series
-writer that produces them in the reference (Writer#write) is a "next" row of SURVEY.md §8(f), not part of this path.
+lossless qualities.  The external-block byte streams are made inside the step by the device data-series writer (W,
+Writer#write of SURVEY.md §8(f) row 1) from the record columns and K3's features; the same streams built with torch at
+set-up time stay as the expected corpus (decode leg, CPU baseline, parity).
 
 Contract: python bench.py --gpus N --steps K --warmup W ; N > 1 under torch.distributed.run, one rank per GPU, each
 rank codes its own shard of the same size (weak scaling; containers are independent, no collective on the data path).
@@ -36,6 +38,8 @@ from cramtools_amd import records as rec
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 READS_PER_CONTAINER = 10000  # CramContext.java:33
 # series of the block corpus: (name, rANS order) — CompressionHeaderFactory#build L82-124
+BLOCK_DTYPE = np.dtype([("in_off", np.int64), ("out_off", np.int64), ("in_len", np.int32), ("out_cap", np.int32),
+                        ("order", np.int32), ("reserved", np.int32)])  # cramgpu_block
 SERIES = [("QS", 1), ("AP", 0), ("RI", 0), ("BA", 1), ("BF", 1), ("CF", 1), ("NS", 1), ("RG", 1), ("RL", 1), ("TS", 1)]
 
 
@@ -121,6 +125,11 @@ def build_workload(dev, n_reads, ref_len, read_len, seed_shift, features_of, n_c
     rg = torch.full((n_reads,), -1, device=dev)
     rl = rs.read_len.to(torch.int64)
     ts = (300 + ((fr >> 11) % 101) - 50) * torch.where(((fr >> 9) & 1) == 0, 1, -1)
+    # the same values as the columns of the records (what Writer#write reads): the device writer makes the streams from
+    # these inside the timed step; the torch-made streams below stay as the expected corpus (decode leg, CPU baseline)
+    cols = rec.RecordColumns(dev, n_reads, multiref=torch.ones(n_cont, dtype=torch.uint8, device=dev), ap_delta=True,
+                             bam_flags=bf, comp_flags=cf, ref_id=ri, read_group=rg, mate_flags=(bf >> 5) & 1, mate_ref=ns,
+                             mate_start=torch.clamp(starts + ts, min=1), tlen=ts)
     series_bytes = {}
     for name, vals in (("AP", ap), ("RI", ri), ("BF", bf), ("CF", cf), ("NS", ns), ("RG", rg), ("RL", rl), ("TS", ts)):
         b, off = synth_torch.itf8(vals)
@@ -167,7 +176,7 @@ def build_workload(dev, n_reads, ref_len, read_len, seed_shift, features_of, n_c
         within = torch.arange(total, device=dev) - torch.repeat_interleave(torch.cumsum(ln, 0) - ln, ln)
         d_in[dst0[rep] + within] = src[lo[rep] + within]
         del rep, within
-    return dict(ref=ref, reads=reads, rs=rs, n_cont=n_cont, blocks=blocks, n_blocks=n_blocks, d_in=d_in,
+    return dict(ref=ref, reads=reads, rs=rs, cols=cols, n_cont=n_cont, blocks=blocks, n_blocks=n_blocks, d_in=d_in,
                 out_bytes=out_bytes, raw_bytes=int(flat_len.sum()), feat_cap=feat_cap, lens=lens_h, max_cap=max(
                     blocks[i].out_cap for i in range(n_blocks)))
 
@@ -175,9 +184,16 @@ def build_workload(dev, n_reads, ref_len, read_len, seed_shift, features_of, n_c
 class Step:
     """Pre-allocated device state of one encode step (nothing is allocated inside the timed region)."""
 
-    def __init__(self, dev, eng, w):
+    def __init__(self, dev, eng, w, writer=True):
         self.dev, self.eng, self.w = dev, eng, w
         n = w["n_blocks"]
+        # W: the data-series writer produces the K1 input arena inside the step (all 30 series of every container; the
+        # ten rANS series are the blocks, the others are what the host would gzip)
+        self.writer = rec.Writer(eng, dev, w["n_cont"], w["d_in"].numel() + 40 * w["reads"].n + 16 * w["feat_cap"] +
+                                 512 * w["n_cont"]) if writer else None
+        self.ids = np.array([_lib.SERIES_ID[name] for name, _ in SERIES])
+        self.blk = np.zeros(n, BLOCK_DTYPE)
+        self.blk["order"] = np.tile(np.array([o for _, o in SERIES], np.int32), w["n_cont"])
         self.d_out = torch.empty(w["out_bytes"], dtype=torch.uint8, device=dev)
         self.d_len = torch.zeros(n, dtype=torch.int32, device=dev)
         self.d_pos = torch.zeros(n, dtype=torch.int64, device=dev)
@@ -202,10 +218,24 @@ class Step:
                                                       self.hist.data_ptr(), s))
         self.feats.count = int(n)
         self.fac.matrices_and_codes(reads, self.feats, self.hist, self.mats)  # F3 on the device, stream-ordered
+        d_in, blocks = w["d_in"], w["blocks"]
+        if self.writer is not None:
+            # W: records + features -> the byte streams of every series; stream lengths back to the host (as the
+            # container headers need them anyway), block descriptors from them
+            self.writer.write(reads, w["cols"], self.feats)
+            off, ln = self.writer.lengths()
+            blk = self.blk
+            blk["in_off"], blk["in_len"] = off[:, self.ids].reshape(-1), ln[:, self.ids].reshape(-1)
+            cap = (1.05 * blk["in_len"].astype(np.float64) + 257.0 * 257.0 * 3.0 + 4.0).astype(np.int32)  # RANS#allocateIfNeeded
+            blk["out_cap"] = cap
+            slot = (cap.astype(np.int64) + 15) // 16 * 16
+            blk["out_off"] = np.cumsum(slot) - slot
+            assert int(blk["out_off"][-1] + slot[-1]) + 16 <= self.d_out.numel()
+            d_in, blocks = self.writer.arena, blk
         # K1 + gather
         if timed:
             self.ev[0].record()
-        self.eng.encode_dev(w["d_in"], self.d_out, w["blocks"], w["n_blocks"], self.d_len, self.d_pos)
+        self.eng.encode_dev(d_in, self.d_out, blocks, w["n_blocks"], self.d_len, self.d_pos)
         if timed:
             self.ev[1].record()
         self.eng.gather_dev(self.d_out, self.d_pos, self.d_len, w["n_blocks"], w["max_cap"], self.d_pack, self.d_pack_off)

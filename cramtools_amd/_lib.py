@@ -73,6 +73,12 @@ class RecordCols(C.Structure):
                 ("cont_ap_base", C.c_void_p), ("ap_delta", C.c_int32), ("reserved", C.c_int32)]
 
 
+class ReadOut(C.Structure):
+    _fields_ = [("read_len", C.c_void_p), ("aln_start", C.c_void_p), ("mapq", C.c_void_p), ("base_off", C.c_void_p),
+                ("bases", C.c_void_p), ("quals", C.c_void_p), ("bases_cap", C.c_int64), ("seq", C.c_void_p),
+                ("seq_off", C.c_void_p), ("seq_cap", C.c_int64)]
+
+
 N_SERIES = 30
 SERIES_ID = dict(BF=0, AP=1, FP=2, FC=3, QS=4, DL=5, BA=6, TN=7, NF=8, RL=9, RG=10, MQ=11, RN=12, NP=13, TS=14, FN=15, BS=16,
                  IN=17, TC=18, MF=19, NS=20, CF=21, TV=22, TM=23, TL=24, RI=25, RS=26, SC=27, HC=28, PD=29)
@@ -141,6 +147,7 @@ SYMBOLS = {
     "cramgpu_tracks_windows": (I32, [I32, P, P, P, P, P, I32, I64, I32, P, P]),
     "cramgpu_merge_quality_features_dev": (I64, [P, I32, P, P, P, P, P, P, P, P]),
     "cramgpu_write_series_dev": (I32, [P, P, P, P, P, I64, P, P, P, P]),
+    "cramgpu_read_series_dev": (I32, [P, I32, I32, P, P, P, P, I64, P, P, P, P, P]),
     "cramgpu_ref_upload": (I32, [P, I32, P, I64]),
     "cramgpu_ref_drop": (I32, [P, I32]),
     "cramgpu_submit_reads": (P, [P, P, C.c_char_p, I32, P]),

@@ -207,6 +207,8 @@ struct cramgpu_ctx {
     DevBuf<int32_t> d_counts;
     DevBuf<int32_t> d_list;
     DevBuf<int64_t> d_total, d_scan_ws;
+    DevBuf<int32_t> d_series_vals, d_series_cnt;   // cramgpu_read_series_dev: parsed values, counts
+    DevBuf<int64_t> d_series_off, d_series_base;  // ... their offsets, per-container output bases
     PinBuf<int64_t> h_total;
     DevBuf<uint8_t> d_maskws, d_codes25;
     DevBuf<unsigned long long> d_prof;  // CRAMGPU_PROF=1
@@ -485,6 +487,7 @@ void cramgpu_close(cramgpu_ctx* c) {
     c->res.release(); c->rcp_tab.release();
     c->d_in.release(); c->d_out.release(); c->d_pack.release(); c->d_len.release(); c->d_pos.release();
     c->d_off.release(); c->d_err.release(); c->h_stage.release(); c->h_len.release(); c->h_off.release();
+    c->d_series_vals.release(); c->d_series_cnt.release(); c->d_series_off.release(); c->d_series_base.release();
     c->d_counts.release(); c->d_list.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
     for (auto& sl : c->small) {
         sl.h.release();
@@ -935,6 +938,31 @@ int32_t cramgpu_write_series_dev(cramgpu_ctx* c, const cramgpu_reads* reads, con
     if (int rc = enter(c, s)) return rc;
     CallScope scope{c, s};
     HIPCHK(launch_write_series(*reads, *cols, *feats, d_arena, arena_cap, d_series_off, d_series_len, d_status, s));
+    return 0;
+}
+
+int32_t cramgpu_read_series_dev(cramgpu_ctx* c, int32_t n_reads, int32_t n_cont, const int32_t* d_cont_first,
+                                const uint8_t* d_arena, const int64_t* d_series_off, const int32_t* d_series_len,
+                                int64_t series_bytes, const cramgpu_record_cols* cols, const cramgpu_read_out* out,
+                                const cramgpu_features* feats, int32_t* d_status, void* stream) {
+    if (!c || n_reads < 0 || n_cont < 1 || !d_cont_first || !d_arena || !d_series_off || !d_series_len || series_bytes < 0 ||
+        !cols || !out || !feats || !d_status)
+        return fail(CRAMGPU_E_ARG, "read_series: bad argument");
+    if (!cols->bam_flags || !cols->comp_flags || !cols->read_group || !cols->mate_flags || !cols->mate_ref || !cols->mate_start ||
+        !cols->tlen || !cols->next_frag || !cols->tag_list || (cols->cont_multiref && !cols->ref_id) || !out->read_len ||
+        !out->aln_start || !out->mapq || !out->base_off || !out->bases || !out->quals || !out->seq || !out->seq_off ||
+        !feats->op || !feats->pos || !feats->a || !feats->b || !feats->off)
+        return fail(CRAMGPU_E_ARG, "read_series: an output column is missing");
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(c->d_series_vals.reserve(read_series_ws_ints(series_bytes, n_cont)));
+    HIPCHK(c->d_series_cnt.reserve((size_t)n_cont * CRAMGPU_N_SERIES));
+    HIPCHK(c->d_series_off.reserve((size_t)n_cont * CRAMGPU_N_SERIES));
+    HIPCHK(c->d_series_base.reserve((size_t)(n_cont + 1) * 3));
+    HIPCHK(launch_read_series(d_arena, d_series_off, d_series_len, n_cont, n_reads, d_cont_first, *cols, *out, *feats,
+                              c->d_series_vals.p, c->d_series_off.p, c->d_series_cnt.p, c->d_series_base.p, d_status, s));
     return 0;
 }
 

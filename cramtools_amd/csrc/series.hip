@@ -380,6 +380,452 @@ __global__ __launch_bounds__(kTile) void series_write_kernel(WArgs A) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Reader: CramRecordReader#read (htsjdk, L59-211; field order as ReaderToBAM.java:64-176) over whole containers.
+//   R0 layout of the value workspace   R1 a thread per (container, series) turns the ITF8 streams into int arrays and
+//   lists the tab-closed items of IN / SC   R2 per-container bases / features / sequence bytes -> offsets of the batch
+//   R3 a workgroup per container, tiles of 256 records: ranks of the records that carry the optional values, prefix
+//   sums of read lengths / start deltas / feature counts, per-record cursors into the byte series (LDS scans as in the
+//   writer), then every thread assembles its record; quality arrays leave as one coalesced copy per tile when the
+//   tile's records all carry one.
+// The ITF8 parse of R1 is sequential per stream (one 8-byte load per value): fine for Illumina-sized containers, slow
+// for a container of 10 kbp reads whose FP stream holds millions of values.
+struct RArgs {
+    const uint8_t* arena;
+    const int64_t* off;
+    const int32_t* len;
+    int32_t n_cont, n_reads;
+    const int32_t* cont_first;  // [n_cont + 1]
+    cramgpu_record_cols c;      // output columns; cont_multiref / cont_ap_base / ap_delta are inputs
+    cramgpu_read_out o;
+    cramgpu_features f;
+    int32_t* vals;       // workspace: parsed values of the integer series, item starts of IN / SC
+    int64_t* vals_off;   // [n_cont][NS]
+    int32_t* vals_cnt;   // [n_cont][NS]
+    int64_t* cont_base;  // [n_cont + 1][3]: bases, features, sequence bytes in front of container c
+    int32_t* status;
+};
+
+__device__ __forceinline__ bool is_int_series(int k) {
+    return k == CRAMGPU_DS_BF || k == CRAMGPU_DS_CF || k == CRAMGPU_DS_RI || k == CRAMGPU_DS_RL || k == CRAMGPU_DS_AP ||
+           k == CRAMGPU_DS_RG || k == CRAMGPU_DS_MF || k == CRAMGPU_DS_NS || k == CRAMGPU_DS_NP || k == CRAMGPU_DS_TS ||
+           k == CRAMGPU_DS_NF || k == CRAMGPU_DS_TL || k == CRAMGPU_DS_FN || k == CRAMGPU_DS_FP || k == CRAMGPU_DS_DL ||
+           k == CRAMGPU_DS_RS || k == CRAMGPU_DS_HC || k == CRAMGPU_DS_PD || k == CRAMGPU_DS_MQ;
+}
+__device__ __forceinline__ bool is_item_series(int k) { return k == CRAMGPU_DS_IN || k == CRAMGPU_DS_SC; }
+
+// R0: workspace slots: a series of n bytes holds at most n values (n + 1 item starts)
+__global__ __launch_bounds__(1024) void series_ws_layout_kernel(RArgs A) {
+    __shared__ int64_t part[1024];
+    __shared__ int64_t carry;
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int32_t c0 = 0; c0 < A.n_cont; c0 += 1024) {
+        const int32_t c = c0 + tid;
+        int64_t t = 0;
+        if (c < A.n_cont)
+            for (int k = 0; k < NS; k++)
+                if (is_int_series(k) || is_item_series(k)) t += (int64_t)A.len[(int64_t)c * NS + k] + 1;
+        part[tid] = t;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int64_t v = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (c < A.n_cont) {
+            int64_t o = carry + part[tid] - t;
+            for (int k = 0; k < NS; k++) {
+                A.vals_off[(int64_t)c * NS + k] = o;
+                if (is_int_series(k) || is_item_series(k)) o += (int64_t)A.len[(int64_t)c * NS + k] + 1;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) carry += part[1023];
+        __syncthreads();
+    }
+}
+
+struct __attribute__((packed)) PackedU64 { unsigned long long v; };
+
+// R1: thread k of workgroup c parses series k of container c
+__global__ __launch_bounds__(32) void series_parse_kernel(RArgs A) {
+    const int32_t c = (int32_t)blockIdx.x;
+    const int k = (int)threadIdx.x;
+    if (k >= NS) return;
+    const int64_t slot = (int64_t)c * NS + k;
+    const uint8_t* p = A.arena + A.off[slot];
+    const int64_t n = A.len[slot];
+    int32_t* out = A.vals + A.vals_off[slot];
+    int32_t cnt = 0;
+    if (is_int_series(k)) {
+        int64_t i = 0;
+        long long sum = 0;
+        while (i < n) {
+            // the streams are 16-byte aligned slots of one arena with 16 bytes of padding behind the last: an 8-byte
+            // load at any byte of a stream stays inside the arena
+            const unsigned long long w = reinterpret_cast<const PackedU64*>(p + i)->v;
+            const uint32_t b1 = (uint32_t)(w & 255u);
+            const int m = b1 < 0x80u ? 1 : b1 < 0xC0u ? 2 : b1 < 0xE0u ? 3 : b1 < 0xF0u ? 4 : 5;
+            if (i + m > n) {
+                *A.status = CRAMGPU_E_CORRUPT;
+                break;
+            }
+            const uint32_t b2 = (uint32_t)(w >> 8) & 255u, b3 = (uint32_t)(w >> 16) & 255u, b4 = (uint32_t)(w >> 24) & 255u,
+                           b5 = (uint32_t)(w >> 32) & 255u;
+            uint32_t v;
+            if (m == 1)
+                v = b1;
+            else if (m == 2)
+                v = ((b1 & 0x7Fu) << 8) | b2;
+            else if (m == 3)
+                v = ((b1 & 0x3Fu) << 16) | (b2 << 8) | b3;
+            else if (m == 4)
+                v = ((b1 & 0x1Fu) << 24) | (b2 << 16) | (b3 << 8) | b4;
+            else
+                v = ((b1 & 0x0Fu) << 28) | (b2 << 20) | (b3 << 12) | (b4 << 4) | (b5 & 0x0Fu);
+            out[cnt++] = (int32_t)v;
+            sum += (int32_t)v;
+            i += m;
+        }
+        if (k == CRAMGPU_DS_RL) A.cont_base[(int64_t)c * 3 + 0] = sum;
+        if (k == CRAMGPU_DS_FN) A.cont_base[(int64_t)c * 3 + 1] = sum;
+    } else if (is_item_series(k)) {
+        out[0] = 0;
+        for (int64_t i = 0; i < n; i++)
+            if (p[i] == '\t') out[++cnt] = (int32_t)(i + 1);
+        if (n > 0 && p[n - 1] != '\t') *A.status = CRAMGPU_E_CORRUPT;
+    }
+    A.vals_cnt[slot] = cnt;
+}
+
+// R2: offsets of the batch.  cont_base[c] = (bases, features, sequence bytes) in front of container c
+__global__ __launch_bounds__(1024) void series_out_layout_kernel(RArgs A) {
+    __shared__ int64_t part[3][1024];
+    __shared__ int64_t carry[3];
+    const int tid = (int)threadIdx.x;
+    if (tid < 3) carry[tid] = 0;
+    __syncthreads();
+    for (int32_t c0 = 0; c0 < A.n_cont; c0 += 1024) {
+        const int32_t c = c0 + tid;
+        int64_t t[3] = {0, 0, 0};
+        if (c < A.n_cont) {
+            t[0] = A.cont_base[(int64_t)c * 3 + 0];
+            t[1] = A.cont_base[(int64_t)c * 3 + 1];
+            const int64_t si = (int64_t)c * NS + CRAMGPU_DS_IN, ss = (int64_t)c * NS + CRAMGPU_DS_SC;
+            t[2] = (int64_t)A.len[si] - A.vals_cnt[si] + (int64_t)A.len[ss] - A.vals_cnt[ss];
+            if (t[0] < 0 || t[1] < 0) {
+                *A.status = CRAMGPU_E_CORRUPT;
+                t[0] = t[1] = 0;
+            }
+        }
+        for (int q = 0; q < 3; q++) part[q][tid] = t[q];
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            int64_t v[3];
+            for (int q = 0; q < 3; q++) v[q] = tid >= d ? part[q][tid - d] : 0;
+            __syncthreads();
+            for (int q = 0; q < 3; q++) part[q][tid] += v[q];
+            __syncthreads();
+        }
+        if (c < A.n_cont)
+            for (int q = 0; q < 3; q++) A.cont_base[(int64_t)c * 3 + q] = carry[q] + part[q][tid] - t[q];
+        __syncthreads();
+        if (tid < 3) carry[tid] += part[tid][1023];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        for (int q = 0; q < 3; q++) A.cont_base[(int64_t)A.n_cont * 3 + q] = carry[q];
+        A.o.base_off[A.n_reads] = carry[0];
+        A.f.off[A.n_reads] = carry[1];
+        A.o.seq_off[A.n_reads] = carry[2];
+        if ((carry[0] > A.o.bases_cap || carry[1] > A.f.cap || carry[2] > A.o.seq_cap) && *A.status == 0)
+            *A.status = CRAMGPU_E_INSUFFICIENT;
+    }
+}
+
+// exclusive scan of NSC rows of 256 values in LDS, a wave per row; totals to tot[]
+template <int NSC>
+__device__ __forceinline__ void tile_scan(uint32_t (*v)[kTile], uint32_t* tot, int wave, int lane) {
+    for (int k = wave; k < NSC; k += kTile / 64) {
+        const uint32_t v0 = v[k][4 * lane], v1 = v[k][4 * lane + 1], v2 = v[k][4 * lane + 2], v3 = v[k][4 * lane + 3];
+        const uint32_t s = v0 + v1 + v2 + v3;
+        uint32_t inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        const uint32_t ex = inc - s;
+        v[k][4 * lane] = ex;
+        v[k][4 * lane + 1] = ex + v0;
+        v[k][4 * lane + 2] = ex + v0 + v1;
+        v[k][4 * lane + 3] = ex + v0 + v1 + v2;
+        if (lane == 63) tot[k] = inc;
+    }
+}
+
+// rows of the three scan rounds of R3
+enum { S_DET = 0, S_DOWN, S_MAP, S_AP, S_RL, S1_N };                                              // round 1
+enum { T_X = 0, T_D, T_N, T_H, T_P, T_I, T_S, T_BA, T_QS, T_SEQ, T_FEAT, S2_N };                  // round 2
+
+__global__ __launch_bounds__(kTile) void series_read_kernel(RArgs A) {
+    __shared__ uint32_t sc[S2_N][kTile];
+    __shared__ uint32_t tot[S2_N];
+    __shared__ long long run1[S1_N];   // running totals of round 1 (AP may be negative: 64-bit signed)
+    __shared__ long long run2[S2_N];
+    __shared__ int64_t job_src[kTile], job_dst[kTile];
+    __shared__ uint32_t job_len[kTile];
+    __shared__ int contig;
+    __shared__ int corrupt;
+    if (*A.status != 0) return;
+    const int32_t c = (int32_t)blockIdx.x;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int32_t first = A.cont_first[c], last = A.cont_first[c + 1];
+    const bool multiref = A.c.cont_multiref != nullptr && A.c.cont_multiref[c] != 0;
+    const int64_t* voff = A.vals_off + (int64_t)c * NS;
+    const int32_t* vcnt = A.vals_cnt + (int64_t)c * NS;
+    const int64_t* soff = A.off + (int64_t)c * NS;
+    const int32_t* slen = A.len + (int64_t)c * NS;
+    if (tid < S1_N) run1[tid] = 0;
+    if (tid < S2_N) run2[tid] = 0;
+    if (tid == 0) corrupt = 0;
+    __syncthreads();
+    const int32_t n_rec = last - first;
+    // every record has BF, CF, RL, AP, RG, TL (and RI in a multi-reference slice)
+    if (vcnt[CRAMGPU_DS_BF] != n_rec || vcnt[CRAMGPU_DS_CF] != n_rec || vcnt[CRAMGPU_DS_RL] != n_rec ||
+        vcnt[CRAMGPU_DS_AP] != n_rec || vcnt[CRAMGPU_DS_RG] != n_rec || vcnt[CRAMGPU_DS_TL] != n_rec ||
+        (multiref && vcnt[CRAMGPU_DS_RI] != n_rec)) {
+        if (tid == 0) *A.status = CRAMGPU_E_CORRUPT;
+        return;
+    }
+    const int64_t base_b = A.cont_base[(int64_t)c * 3 + 0], base_f = A.cont_base[(int64_t)c * 3 + 1],
+                  base_s = A.cont_base[(int64_t)c * 3 + 2];
+    const int32_t ap_base = A.c.cont_ap_base ? A.c.cont_ap_base[c] : 0;
+#define VAL(id, i) (A.vals[voff[id] + (i)])
+    for (int32_t t0 = first; t0 < last; t0 += kTile) {
+        const int32_t r = t0 + tid, k = r - first;
+        const bool live = r < last;
+        uint32_t bf = 0, cf = 0, L = 0;
+        int32_t ap = 0;
+        if (live) {
+            bf = (uint32_t)VAL(CRAMGPU_DS_BF, k);
+            cf = (uint32_t)VAL(CRAMGPU_DS_CF, k);
+            L = (uint32_t)VAL(CRAMGPU_DS_RL, k);
+            ap = VAL(CRAMGPU_DS_AP, k);
+        }
+        const bool det = live && (cf & CRAMGPU_CF_DETACHED);
+        const bool down = live && !det && (cf & CRAMGPU_CF_HAS_MATE_DOWNSTREAM);
+        const bool mapped = live && !(bf & CRAMGPU_BF_SEGMENT_UNMAPPED);
+        // round 1 (AP deltas are summed as two's complement 32-bit words: the carry-free low word is all that is used)
+        sc[S_DET][tid] = det;
+        sc[S_DOWN][tid] = down;
+        sc[S_MAP][tid] = mapped;
+        sc[S_AP][tid] = (uint32_t)ap;
+        sc[S_RL][tid] = L;
+        if (tid == 0) contig = 1;
+        __syncthreads();
+        tile_scan<S1_N>(sc, tot, wave, lane);
+        __syncthreads();
+        const int64_t i_det = run1[S_DET] + sc[S_DET][tid], i_down = run1[S_DOWN] + sc[S_DOWN][tid],
+                      i_map = run1[S_MAP] + sc[S_MAP][tid];
+        const int32_t start = A.c.ap_delta ? (int32_t)((uint32_t)ap_base + (uint32_t)run1[S_AP] + sc[S_AP][tid] + (uint32_t)ap) : ap;
+        const int64_t boff = base_b + run1[S_RL] + sc[S_RL][tid];
+        __syncthreads();
+        if (tid < S1_N) run1[tid] += tot[tid];
+        // counts of the record's features by the series their payload comes from
+        uint32_t nfeat = 0, nx = 0, nd = 0, nn = 0, nh = 0, np = 0, ni = 0, ns = 0, nba = 0, nqs = 0;
+        bool bad = false;
+        int64_t f_loc = 0;  // container-local index of the record's first feature: needs the scan of nfeat first
+        if (mapped) {
+            if (i_map < vcnt[CRAMGPU_DS_FN] && i_map < vcnt[CRAMGPU_DS_MQ])
+                nfeat = (uint32_t)VAL(CRAMGPU_DS_FN, i_map);
+            else
+                bad = true;
+        }
+        sc[T_FEAT][tid] = nfeat;
+        __syncthreads();
+        tile_scan<1>(sc + T_FEAT, tot + T_FEAT, wave, lane);
+        __syncthreads();
+        f_loc = run2[T_FEAT] + sc[T_FEAT][tid];
+        const uint8_t* fc = A.arena + soff[CRAMGPU_DS_FC];
+        if (mapped && !bad) {
+            if (f_loc + nfeat > slen[CRAMGPU_DS_FC] || f_loc + nfeat > vcnt[CRAMGPU_DS_FP]) {
+                bad = true;
+                nfeat = 0;
+            }
+            for (uint32_t j = 0; j < nfeat; j++) {
+                switch (fc[f_loc + j]) {
+                    case 'B': nba++, nqs++; break;
+                    case 'X': nx++; break;
+                    case 'I': ni++; break;
+                    case 'S': ns++; break;
+                    case 'H': nh++; break;
+                    case 'P': np++; break;
+                    case 'D': nd++; break;
+                    case 'N': nn++; break;
+                    case 'i': nba++; break;
+                    case 'Q': nqs++; break;
+                    default: bad = true;
+                }
+            }
+        }
+        const uint32_t ba_arr = (live && !mapped && !(cf & CRAMGPU_CF_UNKNOWN_BASES)) ? L : 0u;
+        const uint32_t qs_arr = (live && (cf & CRAMGPU_CF_FORCE_PRESERVE_QS)) ? L : 0u;
+        __syncthreads();
+        if (tid == 0) run2[T_FEAT] += tot[T_FEAT];
+        sc[T_X][tid] = nx;
+        sc[T_D][tid] = nd;
+        sc[T_N][tid] = nn;
+        sc[T_H][tid] = nh;
+        sc[T_P][tid] = np;
+        sc[T_I][tid] = ni;
+        sc[T_S][tid] = ns;
+        sc[T_BA][tid] = nba + ba_arr;
+        sc[T_QS][tid] = nqs + qs_arr;
+        __syncthreads();
+        tile_scan<T_SEQ>(sc, tot, wave, lane);   // rows T_X .. T_QS
+        __syncthreads();
+        int64_t cx = run2[T_X] + sc[T_X][tid], cd = run2[T_D] + sc[T_D][tid], cn = run2[T_N] + sc[T_N][tid],
+                ch = run2[T_H] + sc[T_H][tid], cp = run2[T_P] + sc[T_P][tid], ci = run2[T_I] + sc[T_I][tid],
+                cs = run2[T_S] + sc[T_S][tid], cba = run2[T_BA] + sc[T_BA][tid], cqs = run2[T_QS] + sc[T_QS][tid];
+        const int64_t cqs0 = cqs;
+        // cursors must stay inside what the streams hold
+        if (live && (cx + nx > slen[CRAMGPU_DS_BS] || cd + nd > vcnt[CRAMGPU_DS_DL] || cn + nn > vcnt[CRAMGPU_DS_RS] ||
+                     ch + nh > vcnt[CRAMGPU_DS_HC] || cp + np > vcnt[CRAMGPU_DS_PD] || ci + ni > vcnt[CRAMGPU_DS_IN] ||
+                     cs + ns > vcnt[CRAMGPU_DS_SC] || cba + nba + ba_arr > slen[CRAMGPU_DS_BA] ||
+                     cqs + nqs + qs_arr > slen[CRAMGPU_DS_QS] || (det && i_det >= vcnt[CRAMGPU_DS_MF]) ||
+                     (det && (i_det >= vcnt[CRAMGPU_DS_NS] || i_det >= vcnt[CRAMGPU_DS_NP] || i_det >= vcnt[CRAMGPU_DS_TS])) ||
+                     (down && i_down >= vcnt[CRAMGPU_DS_NF])))
+            bad = true;
+        // sequence bytes of the record's I / S features
+        uint32_t nseq = 0;
+        if (live && !bad) {
+            for (uint32_t j = 0; j < ni; j++) nseq += (uint32_t)(VAL(CRAMGPU_DS_IN, ci + j + 1) - VAL(CRAMGPU_DS_IN, ci + j) - 1);
+            for (uint32_t j = 0; j < ns; j++) nseq += (uint32_t)(VAL(CRAMGPU_DS_SC, cs + j + 1) - VAL(CRAMGPU_DS_SC, cs + j) - 1);
+        }
+        __syncthreads();
+        if (tid < T_SEQ) run2[tid] += tot[tid];
+        sc[T_SEQ][tid] = nseq;
+        __syncthreads();
+        tile_scan<1>(sc + T_SEQ, tot + T_SEQ, wave, lane);
+        __syncthreads();
+        const int64_t seq0 = base_s + run2[T_SEQ] + sc[T_SEQ][tid];
+        if (bad) corrupt = 1;
+        uint32_t qlen = 0;
+        if (live) {
+            A.c.bam_flags[r] = (int32_t)bf;
+            A.c.comp_flags[r] = (int32_t)cf;
+            if (A.c.ref_id) A.c.ref_id[r] = multiref ? VAL(CRAMGPU_DS_RI, k) : 0;
+            A.o.read_len[r] = (int32_t)L;
+            A.o.aln_start[r] = start;
+            A.c.read_group[r] = VAL(CRAMGPU_DS_RG, k);
+            A.c.tag_list[r] = VAL(CRAMGPU_DS_TL, k);
+            const bool ok = !bad;
+            A.c.mate_flags[r] = det && ok ? VAL(CRAMGPU_DS_MF, i_det) : 0;
+            A.c.mate_ref[r] = det && ok ? VAL(CRAMGPU_DS_NS, i_det) : 0;
+            A.c.mate_start[r] = det && ok ? VAL(CRAMGPU_DS_NP, i_det) : 0;
+            A.c.tlen[r] = det && ok ? VAL(CRAMGPU_DS_TS, i_det) : 0;
+            A.c.next_frag[r] = down && ok ? VAL(CRAMGPU_DS_NF, i_down) : 0;
+            A.o.mapq[r] = mapped && ok ? (uint8_t)VAL(CRAMGPU_DS_MQ, i_map) : (uint8_t)255;
+            A.o.base_off[r] = boff;
+            A.o.seq_off[r] = seq0;
+            A.f.off[r] = base_f + f_loc;
+            if (ok && boff + L <= A.o.bases_cap) {
+                if (mapped && base_f + f_loc + nfeat <= A.f.cap && seq0 + nseq <= A.o.seq_cap) {
+                    const uint8_t* bs = A.arena + soff[CRAMGPU_DS_BS];
+                    const uint8_t* ba = A.arena + soff[CRAMGPU_DS_BA];
+                    const uint8_t* qs = A.arena + soff[CRAMGPU_DS_QS];
+                    int32_t pos = 0;
+                    int64_t sq = seq0;
+                    for (uint32_t j = 0; j < nfeat; j++) {
+                        const int64_t g = base_f + f_loc + j;
+                        const uint8_t o = fc[f_loc + j];
+                        pos += VAL(CRAMGPU_DS_FP, f_loc + j);
+                        int32_t a = 0, b = 0;
+                        switch (o) {
+                            case 'B':
+                                a = ba[cba++];
+                                b = qs[cqs++];
+                                break;
+                            case 'X': a = (int32_t)bs[cx++] << 16; break;
+                            case 'I':
+                            case 'S': {
+                                const int id = o == 'I' ? CRAMGPU_DS_IN : CRAMGPU_DS_SC;
+                                int64_t& cur = o == 'I' ? ci : cs;
+                                const int32_t s0 = VAL(id, cur), s1 = VAL(id, cur + 1);
+                                cur++;
+                                const uint8_t* src = A.arena + soff[id] + s0;
+                                b = s1 - s0 - 1;
+                                a = (int32_t)(sq - seq0);
+                                for (int32_t i = 0; i < b; i++) A.o.seq[sq + i] = src[i];
+                                sq += b;
+                                break;
+                            }
+                            case 'H': a = VAL(CRAMGPU_DS_HC, ch++); break;
+                            case 'P': a = VAL(CRAMGPU_DS_PD, cp++); break;
+                            case 'D': a = VAL(CRAMGPU_DS_DL, cd++); break;
+                            case 'N': a = VAL(CRAMGPU_DS_RS, cn++); break;
+                            case 'i': a = ba[cba++]; break;
+                            case 'Q': a = qs[cqs++]; break;
+                            default: break;
+                        }
+                        A.f.op[g] = o;
+                        A.f.pos[g] = pos;
+                        A.f.a[g] = a;
+                        A.f.b[g] = b;
+                    }
+                } else if (ba_arr) {
+                    const uint8_t* src = A.arena + soff[CRAMGPU_DS_BA] + cba;
+                    for (uint32_t i = 0; i < L; i++) A.o.bases[boff + i] = src[i];
+                }
+                qlen = L;  // the quality array of the record: copied (force-preserved) or filled with 0xFF by the group
+                job_src[tid] = qs_arr ? soff[CRAMGPU_DS_QS] + cqs0 + nqs : -1;  // behind the scores of the record's B / Q features
+                job_dst[tid] = boff;
+            }
+        }
+        job_len[tid] = qlen;
+        __syncthreads();
+        if (tid < 1) run2[T_SEQ] += tot[T_SEQ];
+        if (live && (qlen == 0 || job_src[tid] < 0 ||
+                     (tid > 0 && (job_len[tid - 1] == 0 || job_src[tid] != job_src[tid - 1] + job_len[tid - 1] ||
+                                  job_dst[tid] != job_dst[tid - 1] + job_len[tid - 1]))))
+            contig = 0;
+        __syncthreads();
+        const int32_t cnt = last - t0 < kTile ? last - t0 : kTile;
+        if (contig) {
+            wg_copy(A.o.quals + job_dst[0], A.arena + job_src[0], job_src[cnt - 1] + job_len[cnt - 1] - job_src[0], tid);
+        } else {
+            for (int j = wave; j < cnt; j += kTile / 64) {
+                const uint32_t n = job_len[j];
+                uint8_t* d = A.o.quals + job_dst[j];
+                if (job_src[j] >= 0) {
+                    const uint8_t* s = A.arena + job_src[j];
+                    for (uint32_t i = lane; i < n; i += 64) d[i] = s[i];
+                } else {
+                    for (uint32_t i = lane; i < n; i += 64) d[i] = 0xFF;
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef VAL
+    if (tid == 0) {
+        // every optional value must have found its record
+        if (corrupt || run1[S_DET] != vcnt[CRAMGPU_DS_MF] || run1[S_DOWN] != vcnt[CRAMGPU_DS_NF] ||
+            run1[S_DET] != vcnt[CRAMGPU_DS_NS] || run1[S_DET] != vcnt[CRAMGPU_DS_NP] || run1[S_DET] != vcnt[CRAMGPU_DS_TS] ||
+            run1[S_MAP] != vcnt[CRAMGPU_DS_FN] || run1[S_MAP] != vcnt[CRAMGPU_DS_MQ] || run2[T_FEAT] != slen[CRAMGPU_DS_FC] ||
+            run2[T_FEAT] != vcnt[CRAMGPU_DS_FP] || run2[T_BA] != slen[CRAMGPU_DS_BA] || run2[T_QS] != slen[CRAMGPU_DS_QS] ||
+            run2[T_X] != slen[CRAMGPU_DS_BS] || run2[T_D] != vcnt[CRAMGPU_DS_DL] || run2[T_N] != vcnt[CRAMGPU_DS_RS] ||
+            run2[T_H] != vcnt[CRAMGPU_DS_HC] || run2[T_P] != vcnt[CRAMGPU_DS_PD] || run2[T_I] != vcnt[CRAMGPU_DS_IN] ||
+            run2[T_S] != vcnt[CRAMGPU_DS_SC])
+            *A.status = CRAMGPU_E_CORRUPT;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_write_series(const cramgpu_reads& r, const cramgpu_record_cols& c, const cramgpu_features& f, uint8_t* arena,
@@ -390,5 +836,23 @@ hipError_t launch_write_series(const cramgpu_reads& r, const cramgpu_record_cols
     hipLaunchKernelGGL(series_count_kernel, dim3(r.n_cont), dim3(kTile), 0, s, A);
     hipLaunchKernelGGL(series_layout_kernel, dim3(1), dim3(1024), 0, s, A, r.n_cont);
     hipLaunchKernelGGL(series_write_kernel, dim3(r.n_cont), dim3(kTile), 0, s, A);
+    return hipGetLastError();
+}
+
+size_t read_series_ws_ints(int64_t series_bytes, int32_t n_cont) { return (size_t)(series_bytes + (int64_t)n_cont * CRAMGPU_N_SERIES + 64); }
+
+hipError_t launch_read_series(const uint8_t* arena, const int64_t* d_off, const int32_t* d_len, int32_t n_cont, int32_t n_reads,
+                              const int32_t* d_cont_first, const cramgpu_record_cols& c, const cramgpu_read_out& o,
+                              const cramgpu_features& f, int32_t* ws_vals, int64_t* ws_off, int32_t* ws_cnt, int64_t* ws_base,
+                              int32_t* d_status, hipStream_t s) {
+    RArgs A{arena, d_off, d_len, n_cont, n_reads, d_cont_first, c, o, f, ws_vals, ws_off, ws_cnt, ws_base, d_status};
+    hipError_t e = hipMemsetAsync(d_status, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws_base, 0, (size_t)(n_cont + 1) * 3 * sizeof(int64_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(series_ws_layout_kernel, dim3(1), dim3(1024), 0, s, A);
+    hipLaunchKernelGGL(series_parse_kernel, dim3(n_cont), dim3(32), 0, s, A);
+    hipLaunchKernelGGL(series_out_layout_kernel, dim3(1), dim3(1024), 0, s, A);
+    hipLaunchKernelGGL(series_read_kernel, dim3(n_cont), dim3(kTile), 0, s, A);
     return hipGetLastError();
 }

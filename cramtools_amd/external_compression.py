@@ -131,7 +131,9 @@ class Engine:
     def encode_dev(self, d_in, d_out, blocks, n, d_out_len, d_out_pos, stream=None):
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().cramgpu_rans_encode_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), C.addressof(blocks), n,
+        # blocks: a ctypes array of Block or a numpy structured array of the same layout
+        pb = blocks.ctypes.data if hasattr(blocks, "ctypes") else C.addressof(blocks)
+        _lib.check(_lib.lib().cramgpu_rans_encode_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), pb, n,
                                                       d_out_len.data_ptr(), d_out_pos.data_ptr(), s))
 
     def decode_dev(self, d_in, d_out, blocks, n, d_out_len, stream=None):

@@ -208,6 +208,53 @@ class Writer:
         return self.arena[int(off[c, k]):int(off[c, k]) + int(ln[c, k])].cpu().numpy().tobytes()
 
 
+class CramRecordReader:
+    """htsjdk!encoding/reader/CramRecordReader#read (L59-211) over whole containers (cramgpu_read_series_dev): the
+    streams of every series back into record columns, features, the bytes of I / S features, the bases of unmapped
+    records and the quality arrays (0xFF where a record has none: what CramNormalizer.restore_quality_scores fills)."""
+
+    def __init__(self, engine, device, n_reads, n_cont, bases_cap, feature_cap, seq_cap):
+        torch = _torch()
+        self.engine, self.device, self.n, self.n_cont = engine, device, n_reads, n_cont
+        self.cols = RecordColumns(device, n_reads)
+        self.read_len = torch.zeros(n_reads, dtype=torch.int32, device=device)
+        self.aln_start = torch.zeros(n_reads, dtype=torch.int32, device=device)
+        self.mapq = torch.zeros(n_reads, dtype=torch.uint8, device=device)
+        self.base_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
+        self.bases = torch.zeros(int(bases_cap) + 16, dtype=torch.uint8, device=device)
+        self.quals = torch.zeros(int(bases_cap) + 16, dtype=torch.uint8, device=device)
+        self.seq = torch.zeros(max(int(seq_cap), 1) + 16, dtype=torch.uint8, device=device)
+        self.seq_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
+        self.feats = FeatureBatch(device, n_reads, feature_cap)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self.bases_cap, self.seq_cap = int(bases_cap), max(int(seq_cap), 1)
+
+    def read(self, arena, series_off, series_len, cont_first, series_bytes, multiref=None, ap_base=None, ap_delta=True):
+        """arena / series_off / series_len / cont_first: device tensors (cont_first int32 [n_cont + 1]).  Stream-ordered."""
+        torch = _torch()
+        self.cols.multiref = _dev(multiref, torch.uint8, self.device) if multiref is not None else None
+        self.cols.ap_base = _dev(ap_base, torch.int32, self.device) if ap_base is not None else None
+        self.cols.ap_delta = bool(ap_delta)
+        cs, fs, o = self.cols.struct(), self.feats.struct(), _lib.ReadOut()
+        o.read_len, o.aln_start, o.mapq, o.base_off = (self.read_len.data_ptr(), self.aln_start.data_ptr(), self.mapq.data_ptr(),
+                                                       self.base_off.data_ptr())
+        o.bases, o.quals, o.bases_cap = self.bases.data_ptr(), self.quals.data_ptr(), self.bases_cap
+        o.seq, o.seq_off, o.seq_cap = self.seq.data_ptr(), self.seq_off.data_ptr(), self.seq_cap
+        self._keep = (cont_first, series_off, series_len)
+        _lib.check(_lib.lib().cramgpu_read_series_dev(self.engine.handle, self.n, self.n_cont, cont_first.data_ptr(),
+                                                      arena if isinstance(arena, int) else arena.data_ptr(),
+                                                      series_off.data_ptr(), series_len.data_ptr(), int(series_bytes), C.byref(cs),
+                                                      C.byref(o), C.byref(fs), self.status.data_ptr(), _stream()))
+
+    def check(self):
+        """Synchronises; raises what the device reported; sets feats.count."""
+        st = int(self.status.item())
+        if st != 0:
+            raise _lib.CramGpuError(st, "data-series reader")
+        self.feats.count = int(self.feats.off[self.n].item())
+        return self
+
+
 def substitution_matrix(hist25):
     """SubstitutionMatrix#<init>([[J): 25 counts ([ref][base] over ACGTN) -> 5 header bytes."""
     h = np.ascontiguousarray(hist25, np.int64).reshape(-1)

@@ -338,6 +338,34 @@ int32_t cramgpu_write_series_dev(cramgpu_ctx* ctx, const cramgpu_reads* reads, c
                                  const cramgpu_features* feats, uint8_t* d_arena, int64_t arena_cap, int64_t* d_series_off,
                                  int32_t* d_series_len, int32_t* d_status, void* stream);
 
+/* What the reader produces besides cramgpu_record_cols and cramgpu_features (device arrays). */
+typedef struct {
+    int32_t* read_len;   /* [n_reads] RL */
+    int32_t* aln_start;  /* [n_reads] AP (deltas summed from cont_ap_base) */
+    uint8_t* mapq;       /* [n_reads] MQ (255 for unmapped records, as ReaderToBAM.java:157) */
+    int64_t* base_off;   /* [n_reads + 1] offset of record r in bases / quals: records back to back */
+    uint8_t* bases;      /* bases of unmapped records (BA); mapped records are left for cramgpu_restore_bases_dev */
+    uint8_t* quals;      /* the QS array of force-preserved records, 0xFF elsewhere (what cramgpu_restore_quals_dev expects) */
+    int64_t bases_cap;   /* bytes in bases / quals */
+    uint8_t* seq;        /* bytes of the I / S features (IN, SC) in record order */
+    int64_t* seq_off;    /* [n_reads + 1]; an I / S feature has a = offset relative to seq_off[r], b = length */
+    int64_t seq_cap;
+} cramgpu_read_out;
+
+/* CramRecordReader#read for every record of every container of the batch: the inverse of cramgpu_write_series_dev.
+ * d_cont_first[n_cont + 1] = first record of every container (the slice headers' record counts, summed);
+ * d_series_off / d_series_len as the writer lays them out (any layout will do: offsets are relative to d_arena, every
+ * stream needs 8 readable bytes behind its end); series_bytes = an upper bound of the sum of all stream lengths.
+ * cols: output columns, with cont_multiref / cont_ap_base (slice alignment start; NULL = 0) / ap_delta as inputs.
+ * feats: op / pos / a / b / off filled (X: a = code << 16), feats->off[n_reads] = feature count.
+ * d_status[0] = 0, CRAMGPU_E_CORRUPT (a stream ends early or holds values no record claims, unknown operator) or
+ * CRAMGPU_E_INSUFFICIENT (bases_cap, seq_cap or feats->cap too small; base_off / off / seq_off [n_reads] hold the needs).
+ * Stream-ordered, does not synchronise; the context keeps a workspace of 4 * series_bytes bytes. */
+int32_t cramgpu_read_series_dev(cramgpu_ctx* ctx, int32_t n_reads, int32_t n_cont, const int32_t* d_cont_first,
+                                const uint8_t* d_arena, const int64_t* d_series_off, const int32_t* d_series_len,
+                                int64_t series_bytes, const cramgpu_record_cols* cols, const cramgpu_read_out* out,
+                                const cramgpu_features* feats, int32_t* d_status, void* stream);
+
 /* Q1 result — htsjdk!lossy/PreservationPolicy as a POD (parsed on the host by the caller, see
  * src/main/java/htsjdk/samtools/cram/lossy/QualityScorePreservation.java:167-256). */
 typedef struct {

@@ -158,3 +158,5 @@ def test_series_writer_test_bodies(hostsim, orc, monkeypatch):
     t.test_writer_matches_oracle(orc, 0, [1])
     t.test_writer_matches_oracle(orc, 2, [300, 5, 257])
     t.test_writer_feeds_the_encoder(orc)
+    t.test_reader_matches_oracle_and_inverts_writer(orc, 0, [1])
+    t.test_reader_matches_oracle_and_inverts_writer(orc, 2, [300, 5, 257])

@@ -130,3 +130,72 @@ def test_writer_feeds_the_encoder(orc):
             assert got == orc.rans(want[k], o), k
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed,sizes", [(0, [1]), (1, [300]), (2, [700, 5, 256, 257]), (3, [64, 1, 1000])])
+def test_reader_matches_oracle_and_inverts_writer(orc, seed, sizes):
+    """writer -> reader on the device: every column, feature and array equals what the oracle's CramRecordReader#read makes
+    of the oracle's streams, container by container."""
+    import torch
+    from cramtools_amd import external_compression as xc, records
+    rng = np.random.default_rng(200 + seed)
+    reads, cols, feats, parts = _batch(rng, sizes)
+    n_cont, n = len(sizes), reads.n
+    multiref = np.array([(c + seed) & 1 for c in range(n_cont)], np.uint8)
+    ap_base = np.array([int(p["aln_start"][0]) - (c % 3) for c, p in enumerate(parts)], np.int32)
+    ap_delta = seed != 3
+    eng = xc.Engine(0)
+    try:
+        rc = records.RecordColumns(DEV, n, multiref=multiref, ap_base=ap_base, ap_delta=ap_delta, **cols)
+        w = records.Writer(eng, DEV, n_cont, 8 * int(reads.bases.numel()) + 70 * n + 4096)
+        w.write(reads, rc, feats)
+        w.lengths()
+        cont_first = torch.as_tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)).to(DEV)
+        rd = records.CramRecordReader(eng, DEV, n, n_cont, int(reads.bases.numel()), feats.count + 8, int(reads.bases.numel()))
+        rd.read(w.arena, w.off, w.len, cont_first, int(w.arena.numel()), multiref=multiref, ap_base=ap_base, ap_delta=ap_delta)
+        rd.check()
+        got_f = rd.feats.to_host()
+        r0 = f0 = 0
+        base_off, seq_off = rd.base_off.cpu().numpy(), rd.seq_off.cpu().numpy()
+        g_bases, g_quals, g_seq = rd.bases.cpu().numpy(), rd.quals.cpu().numpy(), rd.seq.cpu().numpy()
+        for c, p in enumerate(parts):
+            streams = orc.write_series(p["cols"], p["read_len"], p["aln_start"], p["mapq"], p["bases"], p["quals"], p["base_off"],
+                                       p["feats"], multiref=bool(multiref[c]), ap_base=int(ap_base[c]), ap_delta=ap_delta)
+            want = orc.read_series(streams, p["n"], multiref=bool(multiref[c]), ap_base=int(ap_base[c]), ap_delta=ap_delta)
+            m, nf = p["n"], want["n_feat"]
+            for k in records.RECORD_COLS:
+                assert np.array_equal(getattr(rd.cols, k)[r0:r0 + m].cpu().numpy(), want[k]), (c, k)
+            assert np.array_equal(rd.read_len[r0:r0 + m].cpu().numpy(), want["read_len"])
+            assert np.array_equal(rd.aln_start[r0:r0 + m].cpu().numpy(), want["aln_start"])
+            assert np.array_equal(rd.mapq[r0:r0 + m].cpu().numpy(), want["mapq"])
+            assert np.array_equal(base_off[r0:r0 + m + 1] - base_off[r0], want["base_off"])
+            assert np.array_equal(seq_off[r0:r0 + m + 1] - seq_off[r0], want["seq_off"])
+            assert np.array_equal(got_f["off"][r0:r0 + m + 1] - f0, want["feat_off"])
+            for k in ("op", "pos", "a", "b"):
+                assert np.array_equal(got_f[k][f0:f0 + nf], want[k][:nf]), (c, k)
+            nb, nsq = int(want["base_off"][m]), int(want["seq_off"][m])
+            b0, s0 = int(base_off[r0]), int(seq_off[r0])
+            assert np.array_equal(g_quals[b0:b0 + nb], want["quals"][:nb])
+            assert np.array_equal(g_seq[s0:s0 + nsq], want["seq"][:nsq])
+            unm = (want["bam_flags"] & 4) != 0
+            for r in np.nonzero(unm & ((want["comp_flags"] & 8) == 0))[0]:
+                o, L = int(want["base_off"][r]), int(want["read_len"][r])
+                assert np.array_equal(g_bases[b0 + o:b0 + o + L], want["bases"][o:o + L])
+            r0 += m
+            f0 += nf
+        assert rd.feats.count == f0
+        # a stream cut short, a capacity too small: reported, no fault
+        w.len[3] -= 1  # container 0, FC... any series: the reader must notice
+        w.len[0] -= 1
+        rd.read(w.arena, w.off, w.len, cont_first, int(w.arena.numel()), multiref=multiref, ap_base=ap_base, ap_delta=ap_delta)
+        with pytest.raises(RuntimeError):
+            rd.check()
+        w.len[3] += 1
+        w.len[0] += 1
+        if feats.count > 4:
+            small = records.CramRecordReader(eng, DEV, n, n_cont, int(reads.bases.numel()), 2, int(reads.bases.numel()))
+            small.read(w.arena, w.off, w.len, cont_first, int(w.arena.numel()), multiref=multiref, ap_base=ap_base, ap_delta=ap_delta)
+            with pytest.raises(RuntimeError):
+                small.check()
+    finally:
+        eng.close()
