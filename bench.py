@@ -247,9 +247,12 @@ class Step:
 class DecodeStep:
     """configs[2]: the decode hot path over the streams one encode step produced (nothing allocated while timed):
       K2  rANS decode of every external block (from the gathered dense arena back into a raw arena),
-      N1  CramNormalizer.restoreReadBases for every read (features + substitution codes of the encode step,
-          whole-reference window per container, matrices on the host as the compression header holds them),
-      N2  CramNormalizer.restoreQualityScores on the decoded QS bytes (force-preserved scores)."""
+      R   the data-series reader (CramRecordReader#read): the decoded rANS series, and the series the reference gzips
+          taken raw from the writer's arena as the host would hand them over, back into record columns, features, I / S
+          bytes and quality arrays,
+      N1  CramNormalizer.restoreReadBases for every read from the READER's columns and features (whole-reference window
+          per container, matrices on the host as the compression header holds them),
+      N2  CramNormalizer.restoreQualityScores on the reader's quality arrays."""
 
     def __init__(self, dev, eng, w, enc):
         self.dev, self.eng, self.w, self.enc = dev, eng, w, enc
@@ -264,10 +267,15 @@ class DecodeStep:
         self.d_len = torch.zeros(n, dtype=torch.int32, device=dev)
         reads = w["reads"]
         self.mats_h = np.ascontiguousarray(enc.mats.cpu().numpy())
-        self.bases = torch.zeros(reads.bases.numel() + 16, dtype=torch.uint8, device=dev)
         self.st_b = torch.zeros(reads.n, dtype=torch.int32, device=dev)
         self.st_q = torch.zeros(reads.n, dtype=torch.int32, device=dev)
-        self.rflags = reads.rflags | 16  # CRAMGPU_RF_FORCE_QS: lossless records carry CF_FORCE_PRESERVE_QS
+        self.reader = None
+        if enc.writer is not None:
+            self.reader = rec.CramRecordReader(eng, dev, reads.n, w["n_cont"], int(reads.bases.numel()), w["feat_cap"],
+                                               16 * w["feat_cap"])
+        else:  # the round-1 form: columns and features of the encode side
+            self.bases = torch.zeros(reads.bases.numel() + 16, dtype=torch.uint8, device=dev)
+            self.rflags = reads.rflags | 16  # CRAMGPU_RF_FORCE_QS: lossless records carry CF_FORCE_PRESERVE_QS
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         self.k2_ms, self.ms = [], []
 
@@ -279,17 +287,31 @@ class DecodeStep:
         self.eng.decode_dev(self.enc.d_pack, self.d_raw, self.blocks, w["n_blocks"], self.d_len)
         if timed:
             self.ev[1].record()
-        fs = self.enc.feats.struct()
-        _lib.check(L.cramgpu_restore_bases_dev(
-            self.eng.handle, reads.n, reads.read_len.data_ptr(), reads.aln_start.data_ptr(), self.rflags.data_ptr(),
-            reads.read_cont.data_ptr(), reads.n_cont, reads.win.data_ptr(), C.byref(fs), reads.bases.data_ptr(),
-            reads.base_off.data_ptr(), int(reads.bases.numel()), w["ref"].data_ptr(), self.mats_h.ctypes.data,
-            self.bases.data_ptr(),
-            reads.base_off.data_ptr(), self.st_b.data_ptr(), s))
-        # the qualities of a read sit in the decoded arena inside its container's QS block (q_off), restored in place
-        _lib.check(L.cramgpu_restore_quals_dev(self.eng.handle, reads.n, reads.read_len.data_ptr(), self.rflags.data_ptr(),
-                                               C.byref(fs), 30, self.d_raw.data_ptr(), self.q_off.data_ptr(),
-                                               self.st_q.data_ptr(), s))
+        if self.reader is not None:
+            rd = self.reader
+            rd.read(self.arena_base, self.r_off, self.r_len, self.cont_first, self.series_bytes, multiref=self.multiref,
+                    ap_base=self.ap_base, ap_delta=True)
+            fs = rd.feats.struct()
+            _lib.check(L.cramgpu_restore_bases_dev(
+                self.eng.handle, reads.n, rd.read_len.data_ptr(), rd.aln_start.data_ptr(), rd.rflags.data_ptr(),
+                reads.read_cont.data_ptr(), reads.n_cont, reads.win.data_ptr(), C.byref(fs), rd.seq.data_ptr(),
+                rd.seq_off.data_ptr(), rd.seq_cap, w["ref"].data_ptr(), self.mats_h.ctypes.data, rd.bases.data_ptr(),
+                rd.base_off.data_ptr(), self.st_b.data_ptr(), s))
+            _lib.check(L.cramgpu_restore_quals_dev(self.eng.handle, reads.n, rd.read_len.data_ptr(), rd.rflags.data_ptr(),
+                                                   C.byref(fs), 30, rd.quals.data_ptr(), rd.base_off.data_ptr(),
+                                                   self.st_q.data_ptr(), s))
+        else:
+            fs = self.enc.feats.struct()
+            _lib.check(L.cramgpu_restore_bases_dev(
+                self.eng.handle, reads.n, reads.read_len.data_ptr(), reads.aln_start.data_ptr(), self.rflags.data_ptr(),
+                reads.read_cont.data_ptr(), reads.n_cont, reads.win.data_ptr(), C.byref(fs), reads.bases.data_ptr(),
+                reads.base_off.data_ptr(), int(reads.bases.numel()), w["ref"].data_ptr(), self.mats_h.ctypes.data,
+                self.bases.data_ptr(),
+                reads.base_off.data_ptr(), self.st_b.data_ptr(), s))
+            # the qualities of a read sit in the decoded arena inside its container's QS block (q_off), restored in place
+            _lib.check(L.cramgpu_restore_quals_dev(self.eng.handle, reads.n, reads.read_len.data_ptr(), self.rflags.data_ptr(),
+                                                   C.byref(fs), 30, self.d_raw.data_ptr(), self.q_off.data_ptr(),
+                                                   self.st_q.data_ptr(), s))
         if timed:
             self.ev[2].record()
             torch.cuda.synchronize()
@@ -297,9 +319,26 @@ class DecodeStep:
             self.ms.append(self.ev[0].elapsed_time(self.ev[2]))
 
     def prepare(self):
-        """Per-read offsets of the quality bytes inside the decoded arena (QS block of the read's container)."""
+        """Reader tables: where every series of every container lies (rANS series in the decoded arena, the others raw in
+        the writer's arena), relative to one base address; or (round-1 form) per-read offsets of the quality bytes."""
         w, reads = self.w, self.w["reads"]
         ns = len(SERIES)
+        if self.reader is not None:
+            wr = self.enc.writer
+            off, ln = wr.lengths()
+            base = wr.arena.data_ptr()
+            r_off = off.copy()
+            in_off = np.array([w["blocks"][i].in_off for i in range(w["n_blocks"])], np.int64).reshape(w["n_cont"], ns)
+            r_off[:, self.enc.ids] = self.d_raw.data_ptr() + in_off - base
+            self.arena_base = base
+            self.r_off = torch.as_tensor(r_off.reshape(-1)).to(self.dev)
+            self.r_len = torch.as_tensor(ln.reshape(-1).copy()).to(self.dev)
+            self.series_bytes = int(ln.sum()) + 64
+            self.cont_first = torch.as_tensor(np.minimum(np.arange(w["n_cont"] + 1, dtype=np.int64) * READS_PER_CONTAINER,
+                                                         reads.n).astype(np.int32)).to(self.dev)
+            self.multiref = w["cols"].multiref
+            self.ap_base = reads.aln_start[self.cont_first[:-1].to(torch.int64)].contiguous()
+            return
         qs_off = torch.as_tensor(np.array([w["blocks"][c * ns].in_off for c in range(w["n_cont"])], np.int64), device=self.dev)
         first = reads.base_off[torch.arange(w["n_cont"], device=self.dev) * READS_PER_CONTAINER]
         cont = reads.read_cont.to(torch.int64)
@@ -314,6 +353,19 @@ class DecodeStep:
         tot = int(w["rs"].read_len.sum().item())
         assert int((self.st_b != 0).sum().item()) == 0, "restoreReadBases reported a status"
         assert int((self.st_q != 0).sum().item()) == 0, "restoreQualityScores reported a status"
+        if self.reader is not None:
+            rd = self.reader.check()
+            assert torch.equal(rd.read_len, reads.read_len) and torch.equal(rd.aln_start, reads.aln_start), "RL / AP"
+            assert torch.equal(rd.base_off[:-1], reads.base_off), "record offsets"
+            for k in rec.RECORD_COLS:
+                assert torch.equal(getattr(rd.cols, k), getattr(w["cols"], k)), k
+            nf = self.enc.feats.count
+            assert rd.feats.count == nf and torch.equal(rd.feats.off, self.enc.feats.off), "feature counts"
+            assert torch.equal(rd.feats.op[:nf], self.enc.feats.op[:nf]) and torch.equal(rd.feats.pos[:nf], self.enc.feats.pos[:nf])
+            assert torch.equal(rd.bases[:tot], reads.bases[:tot]), "restored bases differ from the reads"
+            assert torch.equal(rd.quals[:tot], reads.quals[:tot]), "restored scores differ from the reads"
+            return ("all %d blocks and %d reads round-trip through writer, rANS, reader and normalizer (decoded arena == raw "
+                    "arena, record columns, features, bases and scores == the reads)" % (w["n_blocks"], reads.n))
         assert torch.equal(self.bases[:tot], reads.bases[:tot]), "restored bases differ from the reads"
         return "all %d blocks and %d reads round-trip (decoded arena == raw arena, restored bases == read bases)" % (
             w["n_blocks"], reads.n)

@@ -76,7 +76,7 @@ class RecordCols(C.Structure):
 class ReadOut(C.Structure):
     _fields_ = [("read_len", C.c_void_p), ("aln_start", C.c_void_p), ("mapq", C.c_void_p), ("base_off", C.c_void_p),
                 ("bases", C.c_void_p), ("quals", C.c_void_p), ("bases_cap", C.c_int64), ("seq", C.c_void_p),
-                ("seq_off", C.c_void_p), ("seq_cap", C.c_int64)]
+                ("seq_off", C.c_void_p), ("seq_cap", C.c_int64), ("rflags", C.c_void_p)]
 
 
 N_SERIES = 30

@@ -427,7 +427,7 @@ __global__ __launch_bounds__(1024) void series_ws_layout_kernel(RArgs A) {
         int64_t t = 0;
         if (c < A.n_cont)
             for (int k = 0; k < NS; k++)
-                if (is_int_series(k) || is_item_series(k)) t += (int64_t)A.len[(int64_t)c * NS + k] + 1;
+                if (is_int_series(k) || is_item_series(k)) t += ((int64_t)A.len[(int64_t)c * NS + k] + 4) & ~(int64_t)3;
         part[tid] = t;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1) {
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(1024) void series_ws_layout_kernel(RArgs A) {
             int64_t o = carry + part[tid] - t;
             for (int k = 0; k < NS; k++) {
                 A.vals_off[(int64_t)c * NS + k] = o;
-                if (is_int_series(k) || is_item_series(k)) o += (int64_t)A.len[(int64_t)c * NS + k] + 1;
+                if (is_int_series(k) || is_item_series(k)) o += ((int64_t)A.len[(int64_t)c * NS + k] + 4) & ~(int64_t)3;
             }
         }
         __syncthreads();
@@ -449,57 +449,83 @@ __global__ __launch_bounds__(1024) void series_ws_layout_kernel(RArgs A) {
     }
 }
 
-struct __attribute__((packed)) PackedU64 { unsigned long long v; };
-
-// R1: thread k of workgroup c parses series k of container c
+// R1: thread k of workgroup c parses series k of container c.  A value's position depends on every value before it, so a
+// stream is one serial walk — but the walk must not wait for memory: a thread keeps a 272-byte window of its stream in
+// its own LDS slot (16-byte loads, all in flight together; the 30 lanes of the wave stay in one loop over values, not
+// over bytes) and reads five bytes per value from it.  Slots are 133 words apart: 32 threads at arbitrary offsets of
+// their slots spread over the banks.
+constexpr int kWin = 512;
+constexpr int kSlotWords = 133;  // 512 + 16 bytes (+ 4: an odd stride)
 __global__ __launch_bounds__(32) void series_parse_kernel(RArgs A) {
+    __shared__ uint32_t stage[32 * kSlotWords];
     const int32_t c = (int32_t)blockIdx.x;
     const int k = (int)threadIdx.x;
-    if (k >= NS) return;
-    const int64_t slot = (int64_t)c * NS + k;
-    const uint8_t* p = A.arena + A.off[slot];
-    const int64_t n = A.len[slot];
-    int32_t* out = A.vals + A.vals_off[slot];
+    const bool item = k < NS && is_item_series(k);
+    const bool active = k < NS && (item || is_int_series(k));
+    const int64_t slot = (int64_t)c * NS + (k < NS ? k : 0);
+    const uint8_t* p = A.arena + (active ? A.off[slot] : 0);
+    const int32_t n = active ? A.len[slot] : 0;
+    int32_t* out = A.vals + (active ? A.vals_off[slot] : 0);
     int32_t cnt = 0;
-    if (is_int_series(k)) {
-        int64_t i = 0;
-        long long sum = 0;
-        while (i < n) {
-            // the streams are 16-byte aligned slots of one arena with 16 bytes of padding behind the last: an 8-byte
-            // load at any byte of a stream stays inside the arena
-            const unsigned long long w = reinterpret_cast<const PackedU64*>(p + i)->v;
-            const uint32_t b1 = (uint32_t)(w & 255u);
-            const int m = b1 < 0x80u ? 1 : b1 < 0xC0u ? 2 : b1 < 0xE0u ? 3 : b1 < 0xF0u ? 4 : 5;
-            if (i + m > n) {
-                *A.status = CRAMGPU_E_CORRUPT;
-                break;
+    uint32_t* my = stage + k * kSlotWords;
+    const uint8_t* myb = reinterpret_cast<const uint8_t*>(my);
+    const bool aligned = ((uintptr_t)p & 15) == 0;
+    int32_t i = 0, w0 = -(kWin + 16);
+    long long sum = 0;
+    bool bad = false;
+    if (item) out[0] = 0;
+    // one loop for every lane of the wave: an ITF8 value per turn (integer series) or a byte (IN / SC: a tab closes an
+    // item); the decode is branch-free.  Window [w0, w0 + 528) <- the stream from the 16-byte unit of the cursor on;
+    // when one lane runs out of window every lane refills (from its own cursor): one memory round trip per ~100 turns
+    // of the wave instead of one per lane per window.
+    for (;;) {
+        const bool more = i < n;
+        if (__ballot(more) == 0) break;
+        if (__ballot(more && i - w0 + 5 > kWin + 16) != 0 && more) {
+            w0 = i & ~15;
+            if (aligned) {
+#pragma unroll
+                for (int q = 0; q < (kWin + 16) / 16; q++) {
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (w0 + 16 * q < n) v = *reinterpret_cast<const uint4*>(p + w0 + 16 * q);  // <= 15 bytes of padding read
+                    my[4 * q] = v.x;
+                    my[4 * q + 1] = v.y;
+                    my[4 * q + 2] = v.z;
+                    my[4 * q + 3] = v.w;
+                }
+            } else {
+                uint8_t* wb = reinterpret_cast<uint8_t*>(my);
+                for (int q = 0; q < kWin + 16; q++) wb[q] = w0 + q < n ? p[w0 + q] : (uint8_t)0;
             }
-            const uint32_t b2 = (uint32_t)(w >> 8) & 255u, b3 = (uint32_t)(w >> 16) & 255u, b4 = (uint32_t)(w >> 24) & 255u,
-                           b5 = (uint32_t)(w >> 32) & 255u;
-            uint32_t v;
-            if (m == 1)
-                v = b1;
-            else if (m == 2)
-                v = ((b1 & 0x7Fu) << 8) | b2;
-            else if (m == 3)
-                v = ((b1 & 0x3Fu) << 16) | (b2 << 8) | b3;
-            else if (m == 4)
-                v = ((b1 & 0x1Fu) << 24) | (b2 << 16) | (b3 << 8) | b4;
-            else
-                v = ((b1 & 0x0Fu) << 28) | (b2 << 20) | (b3 << 12) | (b4 << 4) | (b5 & 0x0Fu);
-            out[cnt++] = (int32_t)v;
-            sum += (int32_t)v;
-            i += m;
         }
-        if (k == CRAMGPU_DS_RL) A.cont_base[(int64_t)c * 3 + 0] = sum;
-        if (k == CRAMGPU_DS_FN) A.cont_base[(int64_t)c * 3 + 1] = sum;
-    } else if (is_item_series(k)) {
-        out[0] = 0;
-        for (int64_t i = 0; i < n; i++)
-            if (p[i] == '\t') out[++cnt] = (int32_t)(i + 1);
-        if (n > 0 && p[n - 1] != '\t') *A.status = CRAMGPU_E_CORRUPT;
+        if (more) {
+            const int j = i - w0;
+            const uint32_t b1 = myb[j], b2 = myb[j + 1], b3 = myb[j + 2], b4 = myb[j + 3], b5 = myb[j + 4];
+            const int lead = __clz((int)~(b1 << 24));  // leading one bits of the first byte
+            const int m = item ? 1 : (lead < 4 ? lead : 4) + 1;
+            if (i + m > n) {
+                bad = true;
+                i = n;
+            } else {
+                const unsigned long long W = ((unsigned long long)b1 << 32) | (b2 << 24) | (b3 << 16) | (b4 << 8) | b5;
+                const uint32_t v4 = (uint32_t)(W >> (8 * (5 - m))) & ((1u << (m == 5 ? 0 : 7 * m)) - 1u);  // m <= 4: 7 m bits
+                const uint32_t v5 = ((uint32_t)(W >> 8) << 4) | (b5 & 0x0Fu);
+                const uint32_t v = m == 5 ? v5 : v4;
+                if (item) {
+                    if (b1 == '\t') out[++cnt] = i + 1;
+                    if (i + 1 == n && b1 != '\t') bad = true;  // the last item is not closed
+                } else {
+                    out[cnt++] = (int32_t)v;
+                    sum += (int32_t)v;
+                }
+                i += m;
+            }
+        }
     }
-    A.vals_cnt[slot] = cnt;
+    if (bad) *A.status = CRAMGPU_E_CORRUPT;
+    if (k == CRAMGPU_DS_RL) A.cont_base[(int64_t)c * 3 + 0] = sum;
+    if (k == CRAMGPU_DS_FN) A.cont_base[(int64_t)c * 3 + 1] = sum;
+    if (k < NS) A.vals_cnt[slot] = cnt;
 }
 
 // R2: offsets of the batch.  cont_base[c] = (bases, features, sequence bytes) in front of container c
@@ -579,6 +605,7 @@ __global__ __launch_bounds__(kTile) void series_read_kernel(RArgs A) {
     __shared__ long long run2[S2_N];
     __shared__ int64_t job_src[kTile], job_dst[kTile];
     __shared__ uint32_t job_len[kTile];
+    __shared__ uint8_t job_fill[kTile];  // no array in the stream: the scores are filled with 0xFF (offsets may be negative)
     __shared__ int contig;
     __shared__ int corrupt;
     if (*A.status != 0) return;
@@ -732,6 +759,10 @@ __global__ __launch_bounds__(kTile) void series_read_kernel(RArgs A) {
             A.c.next_frag[r] = down && ok ? VAL(CRAMGPU_DS_NF, i_down) : 0;
             A.o.mapq[r] = mapped && ok ? (uint8_t)VAL(CRAMGPU_DS_MQ, i_map) : (uint8_t)255;
             A.o.base_off[r] = boff;
+            if (A.o.rflags)
+                A.o.rflags[r] = (uint8_t)(((bf & CRAMGPU_BF_SEGMENT_UNMAPPED) ? CRAMGPU_RF_UNMAPPED : 0) |
+                                          ((cf & CRAMGPU_CF_UNKNOWN_BASES) ? CRAMGPU_RF_UNKNOWN_BASES : 0) |
+                                          ((cf & CRAMGPU_CF_FORCE_PRESERVE_QS) ? CRAMGPU_RF_FORCE_QS : 0));
             A.o.seq_off[r] = seq0;
             A.f.off[r] = base_f + f_loc;
             if (ok && boff + L <= A.o.bases_cap) {
@@ -783,14 +814,15 @@ __global__ __launch_bounds__(kTile) void series_read_kernel(RArgs A) {
                     for (uint32_t i = 0; i < L; i++) A.o.bases[boff + i] = src[i];
                 }
                 qlen = L;  // the quality array of the record: copied (force-preserved) or filled with 0xFF by the group
-                job_src[tid] = qs_arr ? soff[CRAMGPU_DS_QS] + cqs0 + nqs : -1;  // behind the scores of the record's B / Q features
+                job_src[tid] = soff[CRAMGPU_DS_QS] + cqs0 + nqs;  // behind the scores of the record's B / Q features
+                job_fill[tid] = qs_arr ? 0 : 1;
                 job_dst[tid] = boff;
             }
         }
         job_len[tid] = qlen;
         __syncthreads();
         if (tid < 1) run2[T_SEQ] += tot[T_SEQ];
-        if (live && (qlen == 0 || job_src[tid] < 0 ||
+        if (live && (qlen == 0 || job_fill[tid] ||
                      (tid > 0 && (job_len[tid - 1] == 0 || job_src[tid] != job_src[tid - 1] + job_len[tid - 1] ||
                                   job_dst[tid] != job_dst[tid - 1] + job_len[tid - 1]))))
             contig = 0;
@@ -802,7 +834,7 @@ __global__ __launch_bounds__(kTile) void series_read_kernel(RArgs A) {
             for (int j = wave; j < cnt; j += kTile / 64) {
                 const uint32_t n = job_len[j];
                 uint8_t* d = A.o.quals + job_dst[j];
-                if (job_src[j] >= 0) {
+                if (!job_fill[j]) {
                     const uint8_t* s = A.arena + job_src[j];
                     for (uint32_t i = lane; i < n; i += 64) d[i] = s[i];
                 } else {
@@ -839,7 +871,7 @@ hipError_t launch_write_series(const cramgpu_reads& r, const cramgpu_record_cols
     return hipGetLastError();
 }
 
-size_t read_series_ws_ints(int64_t series_bytes, int32_t n_cont) { return (size_t)(series_bytes + (int64_t)n_cont * CRAMGPU_N_SERIES + 64); }
+size_t read_series_ws_ints(int64_t series_bytes, int32_t n_cont) { return (size_t)(series_bytes + (int64_t)n_cont * CRAMGPU_N_SERIES * 4 + 64); }
 
 hipError_t launch_read_series(const uint8_t* arena, const int64_t* d_off, const int32_t* d_len, int32_t n_cont, int32_t n_reads,
                               const int32_t* d_cont_first, const cramgpu_record_cols& c, const cramgpu_read_out& o,

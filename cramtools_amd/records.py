@@ -220,6 +220,7 @@ class CramRecordReader:
         self.read_len = torch.zeros(n_reads, dtype=torch.int32, device=device)
         self.aln_start = torch.zeros(n_reads, dtype=torch.int32, device=device)
         self.mapq = torch.zeros(n_reads, dtype=torch.uint8, device=device)
+        self.rflags = torch.zeros(n_reads, dtype=torch.uint8, device=device)
         self.base_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
         self.bases = torch.zeros(int(bases_cap) + 16, dtype=torch.uint8, device=device)
         self.quals = torch.zeros(int(bases_cap) + 16, dtype=torch.uint8, device=device)
@@ -240,6 +241,7 @@ class CramRecordReader:
                                                        self.base_off.data_ptr())
         o.bases, o.quals, o.bases_cap = self.bases.data_ptr(), self.quals.data_ptr(), self.bases_cap
         o.seq, o.seq_off, o.seq_cap = self.seq.data_ptr(), self.seq_off.data_ptr(), self.seq_cap
+        o.rflags = self.rflags.data_ptr()
         self._keep = (cont_first, series_off, series_len)
         _lib.check(_lib.lib().cramgpu_read_series_dev(self.engine.handle, self.n, self.n_cont, cont_first.data_ptr(),
                                                       arena if isinstance(arena, int) else arena.data_ptr(),

@@ -350,12 +350,14 @@ typedef struct {
     uint8_t* seq;        /* bytes of the I / S features (IN, SC) in record order */
     int64_t* seq_off;    /* [n_reads + 1]; an I / S feature has a = offset relative to seq_off[r], b = length */
     int64_t seq_cap;
+    uint8_t* rflags;     /* [n_reads] or NULL: CRAMGPU_RF_UNMAPPED / UNKNOWN_BASES / FORCE_QS from BF / CF, the per-read flags
+                            cramgpu_restore_bases_dev and cramgpu_restore_quals_dev take */
 } cramgpu_read_out;
 
 /* CramRecordReader#read for every record of every container of the batch: the inverse of cramgpu_write_series_dev.
  * d_cont_first[n_cont + 1] = first record of every container (the slice headers' record counts, summed);
  * d_series_off / d_series_len as the writer lays them out (any layout will do: offsets are relative to d_arena, every
- * stream needs 8 readable bytes behind its end); series_bytes = an upper bound of the sum of all stream lengths.
+ * stream needs 16 readable bytes behind its end); series_bytes = an upper bound of the sum of all stream lengths.
  * cols: output columns, with cont_multiref / cont_ap_base (slice alignment start; NULL = 0) / ap_delta as inputs.
  * feats: op / pos / a / b / off filled (X: a = code << 16), feats->off[n_reads] = feature count.
  * d_status[0] = 0, CRAMGPU_E_CORRUPT (a stream ends early or holds values no record claims, unknown operator) or

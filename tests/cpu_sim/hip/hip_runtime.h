@@ -33,6 +33,8 @@ struct uint2 { uint32_t x, y; };
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
 static inline uint2 make_uint2(uint32_t a, uint32_t b) { return uint2{a, b}; }
 static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return uint4{a, b, c, d}; }
+struct alignas(16) int4 { int32_t x, y, z, w; };
+static inline int4 make_int4(int32_t a, int32_t b, int32_t c, int32_t d) { return int4{a, b, c, d}; }
 
 namespace hipsim {
 struct WaveX {
