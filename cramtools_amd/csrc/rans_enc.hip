@@ -8,14 +8,14 @@
 //
 // Execution model.  A CRAM block is one rANS stream whose four interleaved states form four strictly serial
 // dependency chains; byte identity forbids re-blocking, so the only parallelism inside a block is (a) the four
-// states and (b) everything that does not depend on the states.  One wave issues one vector instruction per ~4.4
-// cycles whether or not the instructions depend on each other (scripts/ubench/lat_bench.hip), so the time of a block
-// is (instructions the chain's wave issues per step) x 4.4 cycles x steps: everything that is not the chain is
-// moved OFF the chain's wave.  The kernel is a resident grid of two-wave workgroups pulling blocks (longest first)
+// states and (b) everything that does not depend on the states.  A lone wave issues a vector instruction that depends on
+// its predecessor every 6 cycles (an independent one every 4; scripts/ubench/dec_bench.hip, lat_bench.hip), so the time
+// of a block is (instructions on the chain's critical path per step) x 6 cycles x steps: everything that is not the
+// chain is moved OFF the chain's wave.  The kernel is a resident grid of two-wave workgroups pulling blocks (longest first)
 // from a ticket counter:
 //   wave 1 ("helper")  1. histograms the input (LDS counters, lane-replicated for small alphabets),
 //                      2. normalises, serialises the frequency table, builds packed encoder symbols (a row per lane),
-//                      3. per batch of 32 coding steps (two halves of 16): fetches the symbol/context bytes, looks the symbols up and
+//                      3. per batch of 64 coding steps (four groups of 16): fetches the symbol/context bytes, looks the symbols up and
 //                         expands them into a 16-byte record per (step, state) in an LDS staging buffer; turns the
 //                         states the chain logged for the previous batch into output bytes, placed with a
 //                         ballot/popcount prefix in the reference's emission order (state 3,2,1,0 per step) and
@@ -25,11 +25,12 @@
 //                      steps instead of one per step); the state moves to the next lane with a row_ror:1 DPP move whose
 //                      bank mask leaves "state before my step" in one of four log registers, so that the log of a half
 //                      batch leaves as ONE 4-byte LDS write per lane.  Every lane executes every step (15 of 16 compute
-//                      garbage that is never read): a lone wave issues one vector instruction per ~4.4 cycles whatever
-//                      its EXEC mask, so idle lanes cost nothing and the per-step LDS traffic of a lane-resident state
+//                      garbage that is never read): a vector instruction costs the wave the same whatever its EXEC
+//                      mask, so idle lanes cost nothing and the per-step LDS traffic of a lane-resident state
 //                      is what goes away.  Per step: the DPP move, compare, conditional byte shift, mul_hi, shift,
 //                      24-bit multiply, add — Encoding#RansEncPutSymbol with everything state-independent removed.
-// The two waves meet at one workgroup barrier per batch; staging and log are double buffered.
+// The two waves meet at one workgroup barrier per batch; the staging area is triple buffered (the helper expands batch
+// i+2 while the chain runs batch i and prefetches the records of batch i+1), the log double buffered.
 // Order-1 tables live in LDS over the compacted alphabet (present symbols + 0) when n*(n|1)*12 B fits the table
 // region, else (same dense layout) in a per-workgroup global scratch.
 #include <climits>
