@@ -127,7 +127,7 @@ def build_workload(dev, n_reads, ref_len, read_len, seed_shift, features_of, n_c
     ts = (300 + ((fr >> 11) % 101) - 50) * torch.where(((fr >> 9) & 1) == 0, 1, -1)
     # the same values as the columns of the records (what Writer#write reads): the device writer makes the streams from
     # these inside the timed step; the torch-made streams below stay as the expected corpus (decode leg, CPU baseline)
-    cols = rec.RecordColumns(dev, n_reads, multiref=torch.ones(n_cont, dtype=torch.uint8, device=dev), ap_delta=True,
+    cols = rec.RecordColumns(dev, n_reads, multiref=torch.ones(n_cont, dtype=torch.uint8, device=dev), ap_delta=True, alias_qs=True,
                              bam_flags=bf, comp_flags=cf, ref_id=ri, read_group=rg, mate_flags=(bf >> 5) & 1, mate_ref=ns,
                              mate_start=torch.clamp(starts + ts, min=1), tlen=ts)
     series_bytes = {}
@@ -231,7 +231,11 @@ class Step:
             slot = (cap.astype(np.int64) + 15) // 16 * 16
             blk["out_off"] = np.cumsum(slot) - slot
             assert int(blk["out_off"][-1] + slot[-1]) + 16 <= self.d_out.numel()
-            d_in, blocks = self.writer.arena, blk
+            # aliased QS streams lie in reads.quals (CRAMGPU_WS_ALIAS_QS): all offsets rebased on the lower address
+            p_arena = self.writer.arena.data_ptr()
+            base = min(p_arena, reads.quals.data_ptr()) & ~15
+            blk["in_off"] += p_arena - base
+            d_in, blocks = base, blk
         # K1 + gather
         if timed:
             self.ev[0].record()

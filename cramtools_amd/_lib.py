@@ -70,7 +70,7 @@ class RecordCols(C.Structure):
     _fields_ = [("bam_flags", C.c_void_p), ("comp_flags", C.c_void_p), ("ref_id", C.c_void_p), ("read_group", C.c_void_p),
                 ("mate_flags", C.c_void_p), ("mate_ref", C.c_void_p), ("mate_start", C.c_void_p), ("tlen", C.c_void_p),
                 ("next_frag", C.c_void_p), ("tag_list", C.c_void_p), ("cont_multiref", C.c_void_p),
-                ("cont_ap_base", C.c_void_p), ("ap_delta", C.c_int32), ("reserved", C.c_int32)]
+                ("cont_ap_base", C.c_void_p), ("ap_delta", C.c_int32), ("flags", C.c_int32)]
 
 
 class ReadOut(C.Structure):
@@ -80,6 +80,7 @@ class ReadOut(C.Structure):
 
 
 N_SERIES = 30
+WS_ALIAS_QS = 1
 SERIES_ID = dict(BF=0, AP=1, FP=2, FC=3, QS=4, DL=5, BA=6, TN=7, NF=8, RL=9, RG=10, MQ=11, RN=12, NP=13, TS=14, FN=15, BS=16,
                  IN=17, TC=18, MF=19, NS=20, CF=21, TV=22, TM=23, TL=24, RI=25, RS=26, SC=27, HC=28, PD=29)
 

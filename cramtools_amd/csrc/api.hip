@@ -207,6 +207,7 @@ struct cramgpu_ctx {
     DevBuf<int32_t> d_counts;
     DevBuf<int32_t> d_list;
     DevBuf<int64_t> d_total, d_scan_ws;
+    DevBuf<uint8_t> d_series_alias;                // cramgpu_write_series_dev: containers whose QS is not copied
     DevBuf<int32_t> d_series_vals, d_series_cnt;   // cramgpu_read_series_dev: parsed values, counts
     DevBuf<int64_t> d_series_off, d_series_base;  // ... their offsets, per-container output bases
     PinBuf<int64_t> h_total;
@@ -487,7 +488,7 @@ void cramgpu_close(cramgpu_ctx* c) {
     c->res.release(); c->rcp_tab.release();
     c->d_in.release(); c->d_out.release(); c->d_pack.release(); c->d_len.release(); c->d_pos.release();
     c->d_off.release(); c->d_err.release(); c->h_stage.release(); c->h_len.release(); c->h_off.release();
-    c->d_series_vals.release(); c->d_series_cnt.release(); c->d_series_off.release(); c->d_series_base.release();
+    c->d_series_alias.release(); c->d_series_vals.release(); c->d_series_cnt.release(); c->d_series_off.release(); c->d_series_base.release();
     c->d_counts.release(); c->d_list.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
     for (auto& sl : c->small) {
         sl.h.release();
@@ -937,7 +938,9 @@ int32_t cramgpu_write_series_dev(cramgpu_ctx* c, const cramgpu_reads* reads, con
     hipStream_t s = pick(c, stream);
     if (int rc = enter(c, s)) return rc;
     CallScope scope{c, s};
-    HIPCHK(launch_write_series(*reads, *cols, *feats, d_arena, arena_cap, d_series_off, d_series_len, d_status, s));
+    HIPCHK(c->d_series_alias.reserve((size_t)reads->n_cont));
+    HIPCHK(launch_write_series(*reads, *cols, *feats, d_arena, arena_cap, d_series_off, d_series_len, d_status,
+                               c->d_series_alias.p, s));
     return 0;
 }
 

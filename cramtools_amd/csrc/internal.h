@@ -58,7 +58,7 @@ hipError_t launch_gather(const uint8_t* src, const int64_t* pos, const int32_t* 
 
 // record kernels
 hipError_t launch_write_series(const cramgpu_reads& r, const cramgpu_record_cols& c, const cramgpu_features& f, uint8_t* arena,
-                               int64_t cap, int64_t* d_off, int32_t* d_len, int32_t* d_status, hipStream_t s);
+                               int64_t cap, int64_t* d_off, int32_t* d_len, int32_t* d_status, uint8_t* d_alias, hipStream_t s);
 size_t read_series_ws_ints(int64_t series_bytes, int32_t n_cont);
 hipError_t launch_read_series(const uint8_t* arena, const int64_t* d_off, const int32_t* d_len, int32_t n_cont, int32_t n_reads,
                               const int32_t* d_cont_first, const cramgpu_record_cols& c, const cramgpu_read_out& o,

@@ -63,6 +63,7 @@ struct WArgs {
     int64_t* off;
     int32_t* len;
     int32_t* status;
+    uint8_t* alias;  // [n_cont] workspace: QS of the container is not copied (CRAMGPU_WS_ALIAS_QS)
 };
 
 // first record of container c: the records of a container are contiguous and read_cont ascends
@@ -153,9 +154,11 @@ __device__ __forceinline__ int32_t start_before(const WArgs& A, int32_t r, int32
 
 __global__ __launch_bounds__(kTile) void series_count_kernel(WArgs A) {
     __shared__ uint32_t tot[NS];
+    __shared__ int noalias;
     const int32_t c = (int32_t)blockIdx.x;
     const int tid = (int)threadIdx.x;
     if (tid < NS) tot[tid] = 0;
+    if (tid == 0) noalias = 0;
     __syncthreads();
     const int32_t first = cont_first(A.r, c), last = cont_first(A.r, c + 1);
     const bool multiref = A.c.cont_multiref != nullptr && A.c.cont_multiref[c] != 0;
@@ -163,18 +166,28 @@ __global__ __launch_bounds__(kTile) void series_count_kernel(WArgs A) {
 #pragma unroll
     for (int k = 0; k < NS; k++) acc.v[k] = 0;
     int bad = 0;
+    bool alias_ok = true;
     for (int32_t r = first + tid; r < last; r += kTile) {
         Sizes z;
         record_sizes(A, r, multiref, start_before(A, r, first, c), z, bad);
 #pragma unroll
         for (int k = 0; k < NS; k++) acc.v[k] += z.v[k];
+        // the record adds exactly its array to QS and the next record's array follows it in reads->quals
+        if (z.v[CRAMGPU_DS_QS] != (uint32_t)A.r.read_len[r] || !(A.c.comp_flags[r] & CRAMGPU_CF_FORCE_PRESERVE_QS) ||
+            (r + 1 < last && A.r.base_off[r + 1] != A.r.base_off[r] + A.r.read_len[r]))
+            alias_ok = false;
     }
 #pragma unroll
     for (int k = 0; k < NS; k++)
         if (acc.v[k]) atomicAdd(&tot[k], acc.v[k]);
     if (bad) *A.status = CRAMGPU_E_ARG;
+    if (!alias_ok) noalias = 1;
     __syncthreads();
     if (tid < NS) A.len[(int64_t)c * NS + tid] = (int32_t)tot[tid];
+    // CRAMGPU_WS_ALIAS_QS: the container's QS stream is its records' quality arrays where they lie
+    if (tid == 0)
+        A.alias[c] = (A.c.flags & CRAMGPU_WS_ALIAS_QS) && !noalias && last > first &&
+                     (((uintptr_t)(A.r.quals + A.r.base_off[first])) & 15) == 0;
 }
 
 // offsets: the streams of container 0 in content-id order, then container 1, ...; each on a 16-byte boundary
@@ -188,7 +201,8 @@ __global__ __launch_bounds__(1024) void series_layout_kernel(WArgs A, int32_t n_
         const int32_t c = c0 + tid;
         int64_t t = 0;
         if (c < n_cont)
-            for (int k = 0; k < NS; k++) t += ((int64_t)A.len[(int64_t)c * NS + k] + 15) & ~(int64_t)15;
+            for (int k = 0; k < NS; k++)
+                if (!(k == CRAMGPU_DS_QS && A.alias[c])) t += ((int64_t)A.len[(int64_t)c * NS + k] + 15) & ~(int64_t)15;
         part[tid] = t;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan
@@ -200,6 +214,10 @@ __global__ __launch_bounds__(1024) void series_layout_kernel(WArgs A, int32_t n_
         if (c < n_cont) {
             int64_t o = carry + part[tid] - t;
             for (int k = 0; k < NS; k++) {
+                if (k == CRAMGPU_DS_QS && A.alias[c]) {
+                    A.off[(int64_t)c * NS + k] = (A.r.quals + A.r.base_off[cont_first(A.r, c)]) - A.arena;
+                    continue;
+                }
                 A.off[(int64_t)c * NS + k] = o;
                 o += ((int64_t)A.len[(int64_t)c * NS + k] + 15) & ~(int64_t)15;
             }
@@ -240,6 +258,7 @@ __global__ __launch_bounds__(kTile) void series_write_kernel(WArgs A) {
     if (tid < NS) base[tid] = A.off[(int64_t)c * NS + tid];
     const int32_t first = cont_first(A.r, c), last = cont_first(A.r, c + 1);
     const bool multiref = A.c.cont_multiref != nullptr && A.c.cont_multiref[c] != 0;
+    const bool aliased = A.alias[c] != 0;
     for (int32_t t0 = first; t0 < last; t0 += kTile) {
         const int32_t r = t0 + tid;
         const bool live = r < last;
@@ -348,7 +367,7 @@ __global__ __launch_bounds__(kTile) void series_write_kernel(WArgs A) {
                 for (uint32_t i = 0; i < L; i++) ba[i] = rb[i];
             }
 #undef SP
-            if (cf & CRAMGPU_CF_FORCE_PRESERVE_QS) {  // the quality array: copied by the group below
+            if ((cf & CRAMGPU_CF_FORCE_PRESERVE_QS) && !aliased) {  // the quality array: copied by the group below
                 qlen = L;
                 job_src[tid] = A.r.base_off[r];
                 job_dst[tid] = (int64_t)(qs - A.arena);
@@ -363,7 +382,8 @@ __global__ __launch_bounds__(kTile) void series_write_kernel(WArgs A) {
         if (tid == 0 && qlen == 0) contig = 0;
         __syncthreads();
         const int32_t cnt = last - t0 < kTile ? last - t0 : kTile;
-        if (contig) {
+        if (aliased) {
+        } else if (contig) {
             const int64_t n = job_src[cnt - 1] + job_len[cnt - 1] - job_src[0];
             wg_copy(A.arena + job_dst[0], A.r.quals + job_src[0], n, tid);
         } else {
@@ -861,8 +881,8 @@ __global__ __launch_bounds__(kTile) void series_read_kernel(RArgs A) {
 }  // namespace
 
 hipError_t launch_write_series(const cramgpu_reads& r, const cramgpu_record_cols& c, const cramgpu_features& f, uint8_t* arena,
-                               int64_t cap, int64_t* d_off, int32_t* d_len, int32_t* d_status, hipStream_t s) {
-    WArgs A{r, c, f, arena, cap, d_off, d_len, d_status};
+                               int64_t cap, int64_t* d_off, int32_t* d_len, int32_t* d_status, uint8_t* d_alias, hipStream_t s) {
+    WArgs A{r, c, f, arena, cap, d_off, d_len, d_status, d_alias};
     hipError_t e = hipMemsetAsync(d_status, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(series_count_kernel, dim3(r.n_cont), dim3(kTile), 0, s, A);

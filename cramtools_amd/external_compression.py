@@ -133,7 +133,8 @@ class Engine:
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         # blocks: a ctypes array of Block or a numpy structured array of the same layout
         pb = blocks.ctypes.data if hasattr(blocks, "ctypes") else C.addressof(blocks)
-        _lib.check(_lib.lib().cramgpu_rans_encode_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), pb, n,
+        p_in = d_in if isinstance(d_in, int) else d_in.data_ptr()  # an address: blocks spread over several device buffers
+        _lib.check(_lib.lib().cramgpu_rans_encode_dev(self._h, p_in, d_out.data_ptr(), pb, n,
                                                       d_out_len.data_ptr(), d_out_pos.data_ptr(), s))
 
     def decode_dev(self, d_in, d_out, blocks, n, d_out_len, stream=None):

@@ -154,7 +154,7 @@ class RecordColumns:
     """The CramCompressionRecord fields that reads and features do not hold, as device int32 arrays
     (cramgpu_record_cols): what htsjdk!encoding/writer/Writer#write reads besides bases, scores and features."""
 
-    def __init__(self, device, n_reads, multiref=None, ap_base=None, ap_delta=True, **cols):
+    def __init__(self, device, n_reads, multiref=None, ap_base=None, ap_delta=True, alias_qs=False, **cols):
         torch = _torch()
         self.device, self.n = device, n_reads
         for k in RECORD_COLS:
@@ -163,6 +163,7 @@ class RecordColumns:
         self.multiref = _dev(multiref, torch.uint8, device) if multiref is not None else None
         self.ap_base = _dev(ap_base, torch.int32, device) if ap_base is not None else None
         self.ap_delta = bool(ap_delta)
+        self.alias_qs = bool(alias_qs)
 
     def struct(self):
         c = _lib.RecordCols()
@@ -171,6 +172,7 @@ class RecordColumns:
         c.cont_multiref = self.multiref.data_ptr() if self.multiref is not None else None
         c.cont_ap_base = self.ap_base.data_ptr() if self.ap_base is not None else None
         c.ap_delta = 1 if self.ap_delta else 0
+        c.flags = _lib.WS_ALIAS_QS if getattr(self, "alias_qs", False) else 0
         return c
 
 

@@ -306,6 +306,13 @@ enum {
 #define CRAMGPU_CF_UNKNOWN_BASES 8
 #define CRAMGPU_BF_SEGMENT_UNMAPPED 4
 
+/* Writer option: a container whose QS stream is exactly its records' quality arrays back to back in reads->quals (every
+ * record force-preserved, no B / Q feature, a 16-byte aligned start) gets NO copy: d_series_off points at the arrays
+ * where they lie: an offset relative to d_arena that leaves the arena and may be negative.  A caller that hands the
+ * streams to cramgpu_rans_encode_dev passes the lower of the two addresses (d_arena, reads->quals) as its input arena
+ * and rebases the offsets on it. */
+#define CRAMGPU_WS_ALIAS_QS 1
+
 /* The fields of CramCompressionRecord that cramgpu_reads / cramgpu_features do not hold (device arrays, [n_reads]).
  * The writer reads them, the reader fills them (columns a record does not carry are set to 0). */
 typedef struct {
@@ -323,7 +330,7 @@ typedef struct {
     const int32_t* cont_ap_base;  /* [n_cont] slice alignment start the first AP delta is taken from, or NULL = the
                                      first record's own start (delta 0) */
     int32_t ap_delta;             /* CompressionHeader.AP_seriesDelta */
-    int32_t reserved;
+    int32_t flags;                /* writer options: CRAMGPU_WS_* */
 } cramgpu_record_cols;
 
 /* Writer#write for every record of every container of the batch.  Needs reads->bases, quals, base_off, read_len,
@@ -333,7 +340,7 @@ typedef struct {
  *   d_series_off[c * CRAMGPU_N_SERIES + id], d_series_len[...]   (device)
  * d_status[0] = 0, or CRAMGPU_E_INSUFFICIENT when the streams need more than arena_cap bytes (nothing is written then;
  * d_series_len still holds the lengths), or CRAMGPU_E_ARG for an unknown operator byte.
- * Stream-ordered, does not synchronise, allocates nothing. */
+ * Stream-ordered, does not synchronise; the context keeps one byte per container (allocated on first use). */
 int32_t cramgpu_write_series_dev(cramgpu_ctx* ctx, const cramgpu_reads* reads, const cramgpu_record_cols* cols,
                                  const cramgpu_features* feats, uint8_t* d_arena, int64_t arena_cap, int64_t* d_series_off,
                                  int32_t* d_series_len, int32_t* d_status, void* stream);

@@ -45,7 +45,8 @@ def test_writer_matches_oracle(orc, seed, sizes):
     ap_delta = seed != 3
     eng = xc.Engine(0)
     try:
-        rc = records.RecordColumns(DEV, reads.n, multiref=multiref, ap_base=ap_base, ap_delta=ap_delta, **cols)
+        # alias_qs on for one case: no container of these slices qualifies (not every record keeps its scores), nothing changes
+        rc = records.RecordColumns(DEV, reads.n, multiref=multiref, ap_base=ap_base, ap_delta=ap_delta, alias_qs=seed == 2, **cols)
         w = records.Writer(eng, DEV, n_cont, 8 * int(reads.bases.numel()) + 70 * reads.n + 4096)
         w.write(reads, rc, feats)
         off, ln = w.lengths()
@@ -125,6 +126,28 @@ def test_writer_feeds_the_encoder(orc):
         d_len = torch.zeros(len(ids), dtype=torch.int32, device=DEV)
         d_pos = torch.zeros(len(ids), dtype=torch.int64, device=DEV)
         eng.encode_dev(w.arena, d_out, blocks, len(ids), d_len, d_pos)
+        for i, (k, o) in enumerate(ids):
+            got = d_out[int(d_pos[i]):int(d_pos[i]) + int(d_len[i])].cpu().numpy().tobytes()
+            assert got == orc.rans(want[k], o), k
+        # CRAMGPU_WS_ALIAS_QS: every record keeps its scores and the arrays lie back to back -> QS is not copied, its
+        # offset points at reads.quals; everything else as before; the encoder reads both buffers from the lower address
+        rc2 = records.RecordColumns(DEV, n, alias_qs=True, **cols)
+        w2 = records.Writer(eng, DEV, 1, 4 * int(reads.bases.numel()) + 70 * n + 4096)
+        w2.arena.fill_(0xEE)
+        w2.write(reads, rc2, feats)
+        off2, ln2 = w2.lengths()
+        qs = _lib.SERIES_ID["QS"]
+        assert np.array_equal(ln2, ln)
+        assert w2.arena.data_ptr() + int(off2[0, qs]) == reads.quals.data_ptr() + int(rs.base_off[0])
+        for name in ("BA", "FC", "FP", "BS", "FN", "AP", "TS", "NP", "IN", "SC", "DL", "MQ"):
+            assert w2.series(0, name) == want[_lib.SERIES_ID[name]], name
+        used = int(sum((int(ln2[0, k]) + 15) // 16 * 16 for k in range(30) if k != qs))
+        assert bool((w2.arena[used:] == 0xEE).all())  # no slot for QS, nothing written behind the other streams
+        base = min(w2.arena.data_ptr(), reads.quals.data_ptr()) & ~15
+        for i, (k, _) in enumerate(ids):
+            blocks[i].in_off = int(off2[0, k]) + w2.arena.data_ptr() - base
+        d_out.zero_()
+        eng.encode_dev(base, d_out, blocks, len(ids), d_len, d_pos)
         for i, (k, o) in enumerate(ids):
             got = d_out[int(d_pos[i]):int(d_pos[i]) + int(d_len[i])].cpu().numpy().tobytes()
             assert got == orc.rans(want[k], o), k
