@@ -54,6 +54,11 @@ __device__ __forceinline__ uint8_t* itf8_put(uint8_t* p, uint32_t v) {
     return p + 5;
 }
 
+// lanes below this one that are set in m
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 struct WArgs {
     cramgpu_reads r;
     cramgpu_record_cols c;
@@ -469,83 +474,122 @@ __global__ __launch_bounds__(1024) void series_ws_layout_kernel(RArgs A) {
     }
 }
 
-// R1: thread k of workgroup c parses series k of container c.  A value's position depends on every value before it, so a
-// stream is one serial walk — but the walk must not wait for memory: a thread keeps a 272-byte window of its stream in
-// its own LDS slot (16-byte loads, all in flight together; the 30 lanes of the wave stay in one loop over values, not
-// over bytes) and reads five bytes per value from it.  Slots are 133 words apart: 32 threads at arbitrary offsets of
-// their slots spread over the banks.
-constexpr int kWin = 512;
-constexpr int kSlotWords = 133;  // 512 + 16 bytes (+ 4: an odd stride)
-__global__ __launch_bounds__(32) void series_parse_kernel(RArgs A) {
-    __shared__ uint32_t stage[32 * kSlotWords];
-    const int32_t c = (int32_t)blockIdx.x;
-    const int k = (int)threadIdx.x;
-    const bool item = k < NS && is_item_series(k);
-    const bool active = k < NS && (item || is_int_series(k));
-    const int64_t slot = (int64_t)c * NS + (k < NS ? k : 0);
-    const uint8_t* p = A.arena + (active ? A.off[slot] : 0);
-    const int32_t n = active ? A.len[slot] : 0;
-    int32_t* out = A.vals + (active ? A.vals_off[slot] : 0);
-    int32_t cnt = 0;
-    uint32_t* my = stage + k * kSlotWords;
-    const uint8_t* myb = reinterpret_cast<const uint8_t*>(my);
-    const bool aligned = ((uintptr_t)p & 15) == 0;
-    int32_t i = 0, w0 = -(kWin + 16);
-    long long sum = 0;
-    bool bad = false;
-    if (item) out[0] = 0;
-    // one loop for every lane of the wave: an ITF8 value per turn (integer series) or a byte (IN / SC: a tab closes an
-    // item); the decode is branch-free.  Window [w0, w0 + 528) <- the stream from the 16-byte unit of the cursor on;
-    // when one lane runs out of window every lane refills (from its own cursor): one memory round trip per ~100 turns
-    // of the wave instead of one per lane per window.
-    for (;;) {
-        const bool more = i < n;
-        if (__ballot(more) == 0) break;
-        if (__ballot(more && i - w0 + 5 > kWin + 16) != 0 && more) {
-            w0 = i & ~15;
-            if (aligned) {
-#pragma unroll
-                for (int q = 0; q < (kWin + 16) / 16; q++) {
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (w0 + 16 * q < n) v = *reinterpret_cast<const uint4*>(p + w0 + 16 * q);  // <= 15 bytes of padding read
-                    my[4 * q] = v.x;
-                    my[4 * q + 1] = v.y;
-                    my[4 * q + 2] = v.z;
-                    my[4 * q + 3] = v.w;
-                }
-            } else {
-                uint8_t* wb = reinterpret_cast<uint8_t*>(my);
-                for (int q = 0; q < kWin + 16; q++) wb[q] = w0 + q < n ? p[w0 + q] : (uint8_t)0;
-            }
-        }
-        if (more) {
-            const int j = i - w0;
-            const uint32_t b1 = myb[j], b2 = myb[j + 1], b3 = myb[j + 2], b4 = myb[j + 3], b5 = myb[j + 4];
-            const int lead = __clz((int)~(b1 << 24));  // leading one bits of the first byte
-            const int m = item ? 1 : (lead < 4 ? lead : 4) + 1;
-            if (i + m > n) {
-                bad = true;
-                i = n;
-            } else {
-                const unsigned long long W = ((unsigned long long)b1 << 32) | (b2 << 24) | (b3 << 16) | (b4 << 8) | b5;
-                const uint32_t v4 = (uint32_t)(W >> (8 * (5 - m))) & ((1u << (m == 5 ? 0 : 7 * m)) - 1u);  // m <= 4: 7 m bits
-                const uint32_t v5 = ((uint32_t)(W >> 8) << 4) | (b5 & 0x0Fu);
-                const uint32_t v = m == 5 ? v5 : v4;
-                if (item) {
-                    if (b1 == '\t') out[++cnt] = i + 1;
-                    if (i + 1 == n && b1 != '\t') bad = true;  // the last item is not closed
-                } else {
-                    out[cnt++] = (int32_t)v;
-                    sum += (int32_t)v;
-                }
-                i += m;
-            }
-        }
+// R1: a wave per (container, series).  A value's position depends on every value before it, but only through its FIRST
+// byte: per 64-byte chunk (a byte per lane) four ballots give the masks of the bytes that would open a value of 1..5
+// bytes, and a scalar walk marks the true starts — a whole run of equal-length values per turn (the run's starts are a
+// periodic bit pattern ANDed with the mask of that length: one ctz finds where it breaks), so a stream of same-width
+// values (RL, RG, BF, NS ...) costs one turn per chunk.  The start lanes then decode in parallel (branch-free) and
+// store at cnt + rank.  IN / SC: a tab closes an item.  The stream is staged through LDS 1 KiB at a time (16-byte
+// loads a block ahead, so the walk never waits for memory).
+constexpr int kBlk = 1024;
+__device__ __forceinline__ unsigned long long itf8_pattern(int m) {  // bit j set iff j % m == 0
+    return m == 1 ? ~0ull : m == 2 ? 0x5555555555555555ull : m == 3 ? 0x9249249249249249ull : m == 4 ? 0x1111111111111111ull
+                                                                                                     : 0x1084210842108421ull;
+}
+__global__ __launch_bounds__(64) void series_parse_kernel(RArgs A) {
+    __shared__ __align__(16) uint8_t buf[2][kBlk];
+    const int32_t c = (int32_t)blockIdx.y;
+    const int k = (int)blockIdx.x;
+    const int l = (int)threadIdx.x;
+    const int64_t slot = (int64_t)c * NS + k;
+    const bool item = is_item_series(k);
+    if (!item && !is_int_series(k)) {
+        if (l == 0) A.vals_cnt[slot] = 0;
+        return;
     }
-    if (bad) *A.status = CRAMGPU_E_CORRUPT;
-    if (k == CRAMGPU_DS_RL) A.cont_base[(int64_t)c * 3 + 0] = sum;
-    if (k == CRAMGPU_DS_FN) A.cont_base[(int64_t)c * 3 + 1] = sum;
-    if (k < NS) A.vals_cnt[slot] = cnt;
+    const uint8_t* p = A.arena + A.off[slot];
+    const int32_t n = A.len[slot];
+    int32_t* out = A.vals + A.vals_off[slot];
+    const bool aligned = ((uintptr_t)p & 15) == 0;
+    auto fetch = [&](int32_t blk) -> uint4 {  // bytes [1024 blk + 16 l, +16) of the stream, zeros behind its end
+        const int32_t o = blk * kBlk + 16 * l;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (o < n) {
+            if (aligned) {
+                v = *reinterpret_cast<const uint4*>(p + o);  // <= 15 bytes of the arena's padding read
+            } else {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int j = 0; j < 16; j++)
+                    if (o + j < n) w[j >> 2] |= (uint32_t)p[o + j] << (8 * (j & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            // bytes behind the end read as zero (a value must not borrow them: checked below)
+            if (o + 16 > n) {
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                for (int j = 0; j < 16; j++)
+                    if (o + j >= n) w[j >> 2] &= ~(255u << (8 * (j & 3)));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        return v;
+    };
+    const int32_t n_blk = (n + kBlk - 1) / kBlk;
+    *reinterpret_cast<uint4*>(&buf[0][16 * l]) = fetch(0);
+    *reinterpret_cast<uint4*>(&buf[1][16 * l]) = fetch(1);
+    __syncthreads();
+    int32_t cnt = 0, e = 0;
+    long long acc = 0;
+    bool bad = false;
+    if (item && l == 0) out[0] = 0;
+    for (int32_t blk = 0; blk < n_blk; blk++) {
+        const uint4 ahead = fetch(blk + 2);  // lands in the buffer of this block once the block is done
+        const int32_t c_end = (blk + 1) * kBlk < n ? (blk + 1) * kBlk : n;
+        for (int32_t c0 = blk * kBlk; c0 < c_end; c0 += 64) {
+            const int32_t q = c0 + l;
+            const bool valid = q < n;
+            uint32_t b[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) b[j] = buf[((q + j) >> 10) & 1][(q + j) & (kBlk - 1)];
+            if (item) {
+                const unsigned long long tabs = __ballot(valid && b[0] == '\t');
+                if (valid && b[0] == '\t') out[cnt + 1 + (int32_t)mbcnt64(tabs)] = q + 1;
+                cnt += __popcll(tabs);
+                if (valid && q == n - 1 && b[0] != '\t') bad = true;  // the last item is not closed
+                continue;
+            }
+            const unsigned long long V = __ballot(valid);
+            const unsigned long long G2 = __ballot(valid && b[0] >= 0x80u), G3 = __ballot(valid && b[0] >= 0xC0u),
+                                     G4 = __ballot(valid && b[0] >= 0xE0u), G5 = __ballot(valid && b[0] >= 0xF0u);
+            // the true starts of the chunk: a run of equal-length values per turn
+            unsigned long long S = 0;
+            int32_t pp = e;
+            while (pp < 64 && ((V >> pp) & 1ull)) {
+                const int m = 1 + (int)((G2 >> pp) & 1ull) + (int)((G3 >> pp) & 1ull) + (int)((G4 >> pp) & 1ull) +
+                              (int)((G5 >> pp) & 1ull);
+                const unsigned long long Lm = m == 1 ? V & ~G2 : m == 2 ? G2 & ~G3 : m == 3 ? G3 & ~G4 : m == 4 ? G4 & ~G5 : G5;
+                const unsigned long long pat = itf8_pattern(m);
+                const unsigned long long brk = ~(Lm >> pp) & pat;  // first pattern position that does not open such a value
+                const int t = brk ? __ffsll((long long)brk) - 1 : 64;
+                const unsigned long long take = pat & (t >= 64 ? ~0ull : ((1ull << t) - 1ull));
+                S |= take << pp;
+                pp += m * __popcll(take);
+            }
+            e = pp >= 64 ? pp - 64 : 0;
+            const bool start = (S >> l) & 1ull;
+            const int lead = __clz((int)~(b[0] << 24));
+            const int m = (lead < 4 ? lead : 4) + 1;
+            if (start && q + m > n) bad = true;  // the stream ends inside a value
+            const unsigned long long W = ((unsigned long long)b[0] << 32) | (b[1] << 24) | (b[2] << 16) | (b[3] << 8) | b[4];
+            const uint32_t v4 = (uint32_t)(W >> (8 * (5 - m))) & ((1u << (m == 5 ? 0 : 7 * m)) - 1u);
+            const uint32_t v5 = ((uint32_t)(W >> 8) << 4) | (b[4] & 0x0Fu);
+            const uint32_t v = m == 5 ? v5 : v4;
+            if (start) {
+                out[cnt + (int32_t)mbcnt64(S)] = (int32_t)v;
+                acc += (int32_t)v;
+            }
+            cnt += __popcll(S);
+        }
+        __syncthreads();
+        *reinterpret_cast<uint4*>(&buf[blk & 1][16 * l]) = ahead;
+        __syncthreads();
+    }
+    if (__ballot(bad) != 0 && l == 0) *A.status = CRAMGPU_E_CORRUPT;
+    if (k == CRAMGPU_DS_RL || k == CRAMGPU_DS_FN) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+        if (l == 0) A.cont_base[(int64_t)c * 3 + (k == CRAMGPU_DS_RL ? 0 : 1)] = acc;
+    }
+    if (l == 0) A.vals_cnt[slot] = cnt;
 }
 
 // R2: offsets of the batch.  cont_base[c] = (bases, features, sequence bytes) in front of container c
@@ -903,7 +947,7 @@ hipError_t launch_read_series(const uint8_t* arena, const int64_t* d_off, const 
     e = hipMemsetAsync(ws_base, 0, (size_t)(n_cont + 1) * 3 * sizeof(int64_t), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(series_ws_layout_kernel, dim3(1), dim3(1024), 0, s, A);
-    hipLaunchKernelGGL(series_parse_kernel, dim3(n_cont), dim3(32), 0, s, A);
+    hipLaunchKernelGGL(series_parse_kernel, dim3(NS, n_cont), dim3(64), 0, s, A);
     hipLaunchKernelGGL(series_out_layout_kernel, dim3(1), dim3(1024), 0, s, A);
     hipLaunchKernelGGL(series_read_kernel, dim3(n_cont), dim3(kTile), 0, s, A);
     return hipGetLastError();
