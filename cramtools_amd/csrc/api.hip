@@ -1185,8 +1185,10 @@ int32_t cramgpu_lossy_quals_dev(cramgpu_ctx* c, const cramgpu_reads* reads, cons
     // it is sized from the largest base offset + length, read back once)
     if (reads->max_read_len < 0 || reads->n_bases < 0) return fail(CRAMGPU_E_ARG, "lossy_quals: n_bases / max_read_len unset");
     HIPCHK(c->d_maskws.reserve(reads->max_read_len + 1 > 16384 ? (size_t)reads->n_bases + (size_t)reads->n_reads + 64 : 64));
+    HIPCHK(c->d_list.reserve((size_t)reads->n_reads + 1));  // reads the lane-per-read kernel leaves to the wave kernel
     HIPCHK(launch_lossy_quals(*reads, d_ref, d_wpos, window, (const cramgpu_policy*)d_pol, n_pol, d_scores, d_force,
-                              d_status, c->d_maskws.p, s));
+                              d_status, c->d_maskws.p, c->d_list.p, reinterpret_cast<uint32_t*>(c->d_list.p + reads->n_reads),
+                              s));
     return release_small(slot, s);
 }
 
@@ -1489,7 +1491,9 @@ cramgpu_job* cramgpu_submit_reads(cramgpu_ctx* c, const cramgpu_host_reads* R, c
             up(D.pol, h_pol, sizeof(pol));
             up(D.wpos, h_wpos, (size_t)n * 4);
             if (n > 0) {
-                step(launch_lossy_quals(dr, ref0, D.wpos, window, D.pol, n_pol, D.scores, D.force, D.qstatus, D.mask_ws, s));
+                // K3's list is free again by now on this stream
+                step(launch_lossy_quals(dr, ref0, D.wpos, window, D.pol, n_pol, D.scores, D.force, D.qstatus, D.mask_ws, D.list,
+                                        list_n, s));
                 step(launch_merge_quality(n, D.read_len, D.base_off, D.scores, D.force, D.qstatus, D.F1, D.F2, D.counts, false,
                                           nullptr, s));
             }

@@ -85,8 +85,8 @@ hipError_t launch_restore_quals(int32_t n_reads, const int32_t* read_len, const 
                                 uint8_t default_qs, uint8_t* scores, const int64_t* out_off, int32_t* status,
                                 hipStream_t s);
 hipError_t launch_lossy_quals(const cramgpu_reads& r, const uint8_t* ref, const int32_t* wpos, int32_t window,
-                              const cramgpu_policy* d_pol, int32_t n_pol, uint8_t* scores, uint8_t* force,
-                              int32_t* status, uint8_t* d_mask_ws, hipStream_t s);
+                              const cramgpu_policy* d_pol, int32_t n_pol, uint8_t* scores, uint8_t* force, int32_t* status,
+                              uint8_t* d_mask_ws, int32_t* d_list, uint32_t* d_list_n, hipStream_t s);
 hipError_t launch_merge_quality(int32_t n_reads, const int32_t* read_len, const int64_t* base_off, const uint8_t* scores,
                                 const uint8_t* force, const int32_t* qstatus, cramgpu_features in, cramgpu_features out,
                                 int32_t* d_counts, bool write_pass, const int64_t* d_total_guard, hipStream_t s);

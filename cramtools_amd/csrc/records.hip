@@ -971,10 +971,30 @@ __device__ __forceinline__ bool read_gate(const cramgpu_policy& p, bool unmapped
 __global__ __launch_bounds__(64) void lossy_quals_kernel(cramgpu_reads R, const uint8_t* ref, const int32_t* wpos,
                                                          int32_t window, const cramgpu_policy* pol, int32_t n_pol,
                                                          uint8_t* scores, uint8_t* force, int32_t* status,
-                                                         uint8_t* mask_ws) {
-    __shared__ uint8_t lmask[kMaskLds];
+                                                         uint8_t* mask_ws, int32_t mask_lds, const int32_t* list,
+                                                         const uint32_t* list_n) {
+    // the mask of a read lives in LDS when it fits the launch's dynamic allocation (sized by the batch's longest read, at
+    // most kMaskLds: short reads leave the LDS to many resident waves — a wave per read is bound by the chain of
+    // dependent loads per read, so reads in flight are what counts)
+    CRAMGPU_DYN_LDS(lmask);
+    // The workgroup is ONE wave: its LDS accesses complete in program order, so phases that hand mask bytes from lane to
+    // lane need no barrier — and above all no fence: __threadfence_block() + __syncthreads() also wait for every global
+    // store of the scores (a memory round trip, ten times per read: 82 ms for the 10 M reads of configs[1]).  Only a
+    // mask in global scratch (reads longer than the LDS mask) keeps the fence.
+#define K5_SYNC()                     \
+    do {                              \
+        if (mask_in_lds) {            \
+            CRAMGPU_LOCKSTEP();       \
+        } else {                      \
+            __threadfence_block();    \
+            __syncthreads();          \
+        }                             \
+    } while (0)
     const int lane = threadIdx.x;
-    for (int r = blockIdx.x; r < R.n_reads; r += gridDim.x) {
+    // list != nullptr: only the reads the lane-per-read kernel left to this one
+    const int n_items = list ? (int)*list_n : R.n_reads;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int r = list ? list[it] : it;
         const uint8_t fl = R.rflags[r];
         int st = 0;
         int frc = 0;
@@ -988,7 +1008,8 @@ __global__ __launch_bounds__(64) void lossy_quals_kernel(cramgpu_reads R, const 
             const uint8_t* qs = R.quals + bo;
             const uint8_t* rb = R.bases + bo;
             uint8_t* sc = scores + bo;
-            uint8_t* mask = (L + 1 <= kMaskLds) ? lmask : (mask_ws + bo + r);
+            const bool mask_in_lds = L + 1 <= mask_lds;
+            uint8_t* mask = mask_in_lds ? lmask : (mask_ws + bo + r);
             const int cont = R.read_cont ? R.read_cont[r] : 0;
             const cramgpu_refwin W = R.win[cont];
             const uint8_t* wref = ref + W.ref_off;
@@ -1002,8 +1023,7 @@ __global__ __launch_bounds__(64) void lossy_quals_kernel(cramgpu_reads R, const 
             const int64_t wp = wpos[r];
             bool bad = false;
             for (int i = lane; i < L; i += 64) sc[i] = 0xFF;
-            __threadfence_block();
-            __syncthreads();
+            K5_SYNC();
             for (int k = 0; k < n_pol && !bad; k++) {
                 const cramgpu_policy p = pol[k];
                 if (!read_gate(p, unmapped, mapq)) continue;
@@ -1028,8 +1048,7 @@ __global__ __launch_bounds__(64) void lossy_quals_kernel(cramgpu_reads R, const 
                 }
                 if (start == 0) continue;  // :394-396
                 for (int i = lane; i < L + 1; i += 64) mask[i] = 0;
-                __threadfence_block();
-                __syncthreads();
+                K5_SYNC();
                 for (int c = 0; c < p.n_base_cat && !bad; c++) {
                     const int type = p.base_cat[c];
                     int pos = 0;
@@ -1082,13 +1101,11 @@ __global__ __launch_bounds__(64) void lossy_quals_kernel(cramgpu_reads R, const 
                             if (consumes_read(op)) pos += len;
                             if (consumes_ref(op)) refpos += len;
                             if (type == 3) {  // lane 0's two writes must land before a later category overwrites them
-                                __threadfence_block();
-                                __syncthreads();
+                                K5_SYNC();
                             }
                         }
                     }
-                    __threadfence_block();
-                    __syncthreads();
+                    K5_SYNC();
                 }
                 if (bad) break;
                 int masked = 0;
@@ -1111,8 +1128,7 @@ __global__ __launch_bounds__(64) void lossy_quals_kernel(cramgpu_reads R, const 
                 for (int o = 32; o > 0; o >>= 1) masked += __shfl_xor(masked, o);
                 bad = __ballot(bad) != 0;
                 if (masked > L / 2) frc = 1;  // :486-488 safety latch
-                __threadfence_block();
-                __syncthreads();
+                K5_SYNC();
             }
             if (bad) st = CRAMGPU_E_JAVA_THROWS;
         }
@@ -1120,7 +1136,213 @@ __global__ __launch_bounds__(64) void lossy_quals_kernel(cramgpu_reads R, const 
             force[r] = (uint8_t)frc;
             status[r] = st;
         }
-        __syncthreads();
+        CRAMGPU_LOCKSTEP();
+    }
+#undef K5_SYNC
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K5 for short reads: a lane per read.  A wave per 150-base read spends ~3000 wave instructions on it (strided loops
+// of three turns, a CIGAR walk per category, lock-steps): 56 ms for the 10 M reads of configs[1].  Here a lane walks
+// its read in units of 16 bases: the scores of a unit stay in four registers through every policy (whole-read
+// treatments, then per category a 16-bit mask built from the CIGAR elements that overlap the unit; MATCH / MISMATCH
+// compare 16 bases with one unaligned 16-byte load of the reference), the Illumina-8 table sits in LDS, and the unit
+// leaves as one 16-byte store.  Reads the reference would throw on (a score >= 110 under binning, CIGARs that overrun
+// the read, a window behind the read) and reads longer than kLaneReadMax are handed to the wave kernel through a list,
+// which redoes them from scratch with the exact partial effects.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kLanePolMax = 8;
+
+__device__ __forceinline__ uint32_t eq_mask4(uint32_t a, uint32_t b) {  // bit j = byte j of a and b equal
+    const uint32_t x = a ^ b;
+    const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+    const uint32_t z = ~nz & 0x80808080u;
+    return ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u);
+}
+
+__global__ __launch_bounds__(256) void lossy_quals_lane_kernel(cramgpu_reads R, const uint8_t* ref, const int32_t* wpos,
+                                                               int32_t window, const cramgpu_policy* pol, int32_t n_pol,
+                                                               uint8_t* scores, uint8_t* force, int32_t* status,
+                                                               int32_t* defer, uint32_t* defer_n) {
+    __shared__ cramgpu_policy sp[kLanePolMax];
+    __shared__ uint8_t lut[128];
+    __shared__ uint16_t s_masked[kLanePolMax][256];
+    for (int i = threadIdx.x; i < n_pol * (int)(sizeof(cramgpu_policy) / 4); i += blockDim.x)
+        reinterpret_cast<uint32_t*>(sp)[i] = reinterpret_cast<const uint32_t*>(pol)[i];
+    if (threadIdx.x < 128) lut[threadIdx.x] = threadIdx.x < 110 ? kIllumina8[threadIdx.x] : (uint8_t)0;
+    __syncthreads();
+    const int tid = (int)threadIdx.x;
+    const int stride = (int)(gridDim.x * blockDim.x);
+    for (int r = (int)(blockIdx.x * blockDim.x) + tid; r < R.n_reads; r += stride) {
+        const uint8_t fl = R.rflags[r];
+        if (fl & CRAMGPU_RF_SKIP) {
+            force[r] = 0;
+            status[r] = 2;
+            continue;
+        }
+        if (fl & CRAMGPU_RF_NULL_QUALS) {  // :277-281
+            force[r] = 0;
+            status[r] = 1;
+            continue;
+        }
+        const int L = R.read_len[r];
+        const int64_t bo = R.base_off[r];
+        const int32_t start = R.aln_start[r];
+        const int nc = R.n_cigar[r];
+        const uint32_t* cg = R.cigar + R.cigar_off[r];
+        const int64_t wp = wpos[r];
+        // reads this kernel does not decide: too long, or any condition under which the reference throws half way
+        bool leave = L > kLaneReadMax || (start != 0 && (int64_t)start - wp < 0);
+        {
+            int pos = 0;
+            for (int e = 0; e < nc && !leave; e++) {
+                const uint32_t ce = cg[e];
+                const int op = (int)(ce & 15u), len = (int)(ce >> 4);
+                if (op == OP_D && pos >= L) leave = true;
+                if (consumes_read(op)) {
+                    if (pos + len > L) leave = true;
+                    pos += len;
+                }
+            }
+        }
+        const uint8_t* qs = R.quals + bo;
+        const uint8_t* rb = R.bases + bo;
+        uint8_t* sc = scores + bo;
+        const int cont = R.read_cont ? R.read_cont[r] : 0;
+        const cramgpu_refwin W = R.win[cont];
+        const uint8_t* wref = ref + W.ref_off;
+        const int64_t contig_len = W.ref_start0 + W.ref_len;
+        const int64_t Wn = window < contig_len ? window : contig_len;
+        const bool unmapped = (fl & CRAMGPU_RF_UNMAPPED) != 0;
+        const int mapq = R.mapq[r];
+        for (int k = 0; k < n_pol; k++) s_masked[k][tid] = 0;
+        for (int u0 = 0; u0 < L && !leave; u0 += 16) {
+            const int nb = L - u0 < 16 ? L - u0 : 16;
+            const uint32_t valid = nb == 16 ? 0xFFFFu : (1u << nb) - 1u;
+            uint32_t q[4], b[4], o[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (bo + u0 + 16 <= R.n_bases) {
+                const PackedU32x4 t = *reinterpret_cast<const PackedU32x4*>(qs + u0);
+                q[0] = t.v[0], q[1] = t.v[1], q[2] = t.v[2], q[3] = t.v[3];
+                const PackedU32x4 tb = *reinterpret_cast<const PackedU32x4*>(rb + u0);
+                b[0] = tb.v[0], b[1] = tb.v[1], b[2] = tb.v[2], b[3] = tb.v[3];
+            } else {
+                q[0] = q[1] = q[2] = q[3] = b[0] = b[1] = b[2] = b[3] = 0;
+                for (int j = 0; j < nb; j++) {
+                    q[j >> 2] |= (uint32_t)qs[u0 + j] << (8 * (j & 3));
+                    b[j >> 2] |= (uint32_t)rb[u0 + j] << (8 * (j & 3));
+                }
+            }
+            // a score >= 110 throws under binning (Binning.java:63-71): such reads go to the wave kernel
+            uint32_t big = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t h = (((q[c] & 0x7F7F7F7Fu) + 0x12121212u) | q[c]) & 0x80808080u;
+                const int left = nb - 4 * c;
+                big |= left >= 4 ? h : left <= 0 ? 0u : h & ((1u << (8 * left)) - 1u);
+            }
+            if (big) {
+                leave = true;
+                break;
+            }
+            for (int k = 0; k < n_pol; k++) {
+                const cramgpu_policy& p = sp[k];
+                if (!read_gate(p, unmapped, mapq)) continue;
+                uint32_t m16;
+                if (p.n_base_cat == 0) {  // :362-388 whole-read treatment
+                    if (p.treatment == 2) continue;
+                    m16 = valid;
+                } else {
+                    if (start == 0) continue;  // :394-396
+                    m16 = 0;
+                    for (int c = 0; c < p.n_base_cat; c++) {
+                        const int type = p.base_cat[c];
+                        if (type == 4) {  // PILEUP against all-zero tracks
+                            if (0 > p.base_param[c]) m16 = valid;
+                            continue;
+                        }
+                        int pos = 0;
+                        int64_t refpos = start;
+                        for (int e = 0; e < nc; e++) {
+                            const uint32_t ce = cg[e];
+                            const int op = (int)(ce & 15u), len = (int)(ce >> 4);
+                            const bool cr = consumes_read(op);
+                            // positions of the element inside the unit: bits [lo, hi)
+                            int lo = pos - u0, hi = pos + (cr ? len : 0) - u0;
+                            lo = lo < 0 ? 0 : lo;
+                            hi = hi > nb ? nb : hi;
+                            const uint32_t span = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+                            if (type == 3) {
+                                if (op == OP_D) {  // pos < L was checked above
+                                    if (pos >= u0 && pos < u0 + nb) m16 |= 1u << (pos - u0);
+                                    if (pos + 1 < L && pos + 1 >= u0 && pos + 1 < u0 + nb) m16 |= 1u << (pos + 1 - u0);
+                                }
+                            } else if (type == 1 || type == 2) {
+                                if (cr && span) {
+                                    // byte j of the unit faces reference position refpos + (u0 + j - pos)
+                                    const int64_t rp0 = refpos + (u0 - pos);           // 1-based position facing byte 0
+                                    const int64_t gi0 = rp0 - 1 - W.ref_start0;        // its window index
+                                    uint32_t eq;
+                                    if (gi0 + lo >= 0 && gi0 + hi <= W.ref_len && rp0 + hi - 1 - wp < Wn && gi0 >= 0 &&
+                                        gi0 + 16 <= W.ref_len) {
+                                        const PackedU32x4 t = *reinterpret_cast<const PackedU32x4*>(wref + gi0);
+                                        eq = eq_mask4(b[0], t.v[0]) | (eq_mask4(b[1], t.v[1]) << 4) | (eq_mask4(b[2], t.v[2]) << 8) |
+                                             (eq_mask4(b[3], t.v[3]) << 12);
+                                    } else {
+                                        eq = 0;
+                                        for (int j = lo; j < hi; j++) {
+                                            const int64_t rp = rp0 + j, gi = gi0 + j;
+                                            const uint8_t tb = (rp - wp < Wn && gi >= 0 && gi < W.ref_len) ? wref[gi] : (uint8_t)'N';
+                                            if ((uint8_t)(b[j >> 2] >> (8 * (j & 3))) == tb) eq |= 1u << j;
+                                        }
+                                    }
+                                    const uint32_t val = type == 1 ? eq : ~eq;
+                                    m16 = (m16 & ~span) | (val & span);
+                                }
+                            } else if (type == 6) {
+                                if (op == OP_I) m16 |= span;
+                            } else if (type == 5) {  // LOWER_COVERAGE against all-zero tracks
+                                if (op == OP_M || op == OP_EQ || op == OP_X) m16 = 0 < p.base_param[c] ? (m16 | span) : (m16 & ~span);
+                            }
+                            if (cr) pos += len;
+                            if (consumes_ref(op)) refpos += len;
+                        }
+                    }
+                    s_masked[k][tid] += (uint16_t)__popc(m16 & valid);
+                }
+                m16 &= valid;
+                if (m16 == 0) continue;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (!((m16 >> j) & 1u)) continue;
+                    const uint32_t qb = (q[j >> 2] >> (8 * (j & 3))) & 255u;
+                    const uint32_t v = p.treatment == 1 ? lut[qb] : p.treatment == 2 ? 0xFFu : qb;
+                    o[j >> 2] = (o[j >> 2] & ~(255u << (8 * (j & 3)))) | (v << (8 * (j & 3)));
+                }
+            }
+            if (nb == 16) {
+                PackedU32x4 t;
+                t.v[0] = o[0], t.v[1] = o[1], t.v[2] = o[2], t.v[3] = o[3];
+                *reinterpret_cast<PackedU32x4*>(sc + u0) = t;
+            } else {
+                for (int j = 0; j < nb; j++) sc[u0 + j] = (uint8_t)(o[j >> 2] >> (8 * (j & 3)));
+            }
+        }
+        if (leave) {
+            defer[atomicAdd(defer_n, 1u)] = r;
+            continue;
+        }
+        int frc = 0;
+        for (int k = 0; k < n_pol; k++) {
+            const cramgpu_policy& p = sp[k];
+            if (!read_gate(p, unmapped, mapq)) continue;
+            if (p.n_base_cat == 0) {
+                frc = p.treatment == 2 ? 0 : 1;
+            } else if (start != 0 && (int)s_masked[k][tid] > L / 2) {
+                frc = 1;  // :486-488 safety latch
+            }
+        }
+        force[r] = (uint8_t)frc;
+        status[r] = 0;
     }
 }
 
@@ -1300,10 +1522,26 @@ hipError_t launch_restore_quals(int32_t n_reads, const int32_t* read_len, const 
 
 hipError_t launch_lossy_quals(const cramgpu_reads& r, const uint8_t* ref, const int32_t* wpos, int32_t window,
                               const cramgpu_policy* d_pol, int32_t n_pol, uint8_t* scores, uint8_t* force,
-                              int32_t* status, uint8_t* d_mask_ws, hipStream_t s) {
-    int grid = r.n_reads < g_n_cu * 8 ? (r.n_reads > 0 ? r.n_reads : 1) : g_n_cu * 8;
-    hipLaunchKernelGGL(lossy_quals_kernel, dim3(grid), dim3(64), 0, s, r, ref, wpos, window, d_pol, n_pol, scores, force,
-                       status, d_mask_ws);
+                              int32_t* status, uint8_t* d_mask_ws, int32_t* d_list, uint32_t* d_list_n, hipStream_t s) {
+    const int mask_lds = r.max_read_len + 1 <= kMaskLds ? ((r.max_read_len + 1 + 255) & ~255) : kMaskLds;
+    const int per_cu = mask_lds <= 4096 ? 32 : 8;  // single-wave workgroups resident per CU
+    int grid = r.n_reads < g_n_cu * per_cu ? (r.n_reads > 0 ? r.n_reads : 1) : g_n_cu * per_cu;
+    static const bool lane_ok = [] {
+        const char* e = getenv("CRAMGPU_K5_LANE");
+        return !(e && atoi(e) == 0);
+    }();
+    if (lane_ok && r.max_read_len <= kLaneReadMax && n_pol <= kLanePolMax && d_list && d_list_n) {
+        // short reads: a lane per read; what it leaves (reads the reference throws on) goes to the wave kernel
+        hipError_t e = hipMemsetAsync(d_list_n, 0, sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(lossy_quals_lane_kernel, dim3(lane_grid(r.n_reads)), dim3(256), 0, s, r, ref, wpos, window, d_pol, n_pol,
+                           scores, force, status, d_list, d_list_n);
+        hipLaunchKernelGGL(lossy_quals_kernel, dim3(grid < 256 ? grid : 256), dim3(64), (size_t)mask_lds, s, r, ref, wpos, window,
+                           d_pol, n_pol, scores, force, status, d_mask_ws, mask_lds, d_list, d_list_n);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(lossy_quals_kernel, dim3(grid), dim3(64), (size_t)mask_lds, s, r, ref, wpos, window, d_pol, n_pol, scores,
+                       force, status, d_mask_ws, mask_lds, (const int32_t*)nullptr, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 
