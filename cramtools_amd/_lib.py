@@ -85,6 +85,20 @@ SERIES_ID = dict(BF=0, AP=1, FP=2, FC=3, QS=4, DL=5, BA=6, TN=7, NF=8, RL=9, RG=
                  IN=17, TC=18, MF=19, NS=20, CF=21, TV=22, TM=23, TL=24, RI=25, RS=26, SC=27, HC=28, PD=29)
 
 
+class BamCols(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("ref_id", "aln_start", "aln_end", "mapq", "bam_flags", "mate_flags", "mate_ref",
+                                          "mate_start", "tlen", "read_len", "base_off", "bases", "quals", "qual_status",
+                                          "n_cigar", "cigar_off", "cigar", "names", "name_off")] + \
+               [("name_base", C.c_int64), ("tags", C.c_void_p), ("tag_off", C.c_void_p)]
+
+
+class BamOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("ref_id", "aln_start", "mapq", "bam_flags", "mate_ref", "mate_start", "tlen",
+                                          "read_len", "base_off", "bases", "quals")] + [("bases_cap", C.c_int64)] + \
+               [(k, C.c_void_p) for k in ("n_cigar", "cigar_off", "cigar")] + [("cigar_cap", C.c_int64)] + \
+               [(k, C.c_void_p) for k in ("aln_span", "rflags", "name_off", "name_len", "tag_off", "tag_len")]
+
+
 class HostReads(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("n_cont", C.c_int32), ("n_bases", C.c_int64), ("n_cigar_ops", C.c_int64),
                 ("bases", C.c_void_p), ("quals", C.c_void_p), ("read_len", C.c_void_p), ("aln_start", C.c_void_p),
@@ -149,6 +163,11 @@ SYMBOLS = {
     "cramgpu_merge_quality_features_dev": (I64, [P, I32, P, P, P, P, P, P, P, P]),
     "cramgpu_write_series_dev": (I32, [P, P, P, P, P, I64, P, P, P, P]),
     "cramgpu_read_series_dev": (I32, [P, I32, I32, P, P, P, P, I64, P, P, P, P, P]),
+    "cramgpu_cigars_dev": (I32, [P, I32, P, P, P, P, P, P, P, I64, P, P, P]),
+    "cramgpu_restore_mates_dev": (I32, [P, I32, I32, P, P, P, P, P, P, P]),
+    "cramgpu_bam_encode_dev": (I32, [P, I32, P, P, I64, P, P, P]),
+    "cramgpu_bam_decode_dev": (I32, [P, I32, P, P, P, P, P]),
+    "cramgpu_bam_index": (I64, [P, I64, P, I64]),
     "cramgpu_ref_upload": (I32, [P, I32, P, I64]),
     "cramgpu_ref_drop": (I32, [P, I32]),
     "cramgpu_submit_reads": (P, [P, P, C.c_char_p, I32, P]),

@@ -208,6 +208,8 @@ struct cramgpu_ctx {
     DevBuf<int32_t> d_list;
     DevBuf<int64_t> d_total, d_scan_ws;
     DevBuf<uint8_t> d_series_alias;                // cramgpu_write_series_dev: containers whose QS is not copied
+    DevBuf<uint32_t> d_mate_prev;                  // cramgpu_restore_mates_dev: records pointing at a record
+    DevBuf<uint8_t> d_mate_serial;                 //   containers whose chains share records
     DevBuf<int32_t> d_series_vals, d_series_cnt;   // cramgpu_read_series_dev: parsed values, counts
     DevBuf<int64_t> d_series_off, d_series_base;  // ... their offsets, per-container output bases
     PinBuf<int64_t> h_total;
@@ -488,6 +490,7 @@ void cramgpu_close(cramgpu_ctx* c) {
     c->res.release(); c->rcp_tab.release();
     c->d_in.release(); c->d_out.release(); c->d_pack.release(); c->d_len.release(); c->d_pos.release();
     c->d_off.release(); c->d_err.release(); c->h_stage.release(); c->h_len.release(); c->h_off.release();
+    c->d_mate_prev.release(); c->d_mate_serial.release();
     c->d_series_alias.release(); c->d_series_vals.release(); c->d_series_cnt.release(); c->d_series_off.release(); c->d_series_base.release();
     c->d_counts.release(); c->d_list.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
     for (auto& sl : c->small) {
@@ -967,6 +970,93 @@ int32_t cramgpu_read_series_dev(cramgpu_ctx* c, int32_t n_reads, int32_t n_cont,
     HIPCHK(launch_read_series(d_arena, d_series_off, d_series_len, n_cont, n_reads, d_cont_first, *cols, *out, *feats,
                               c->d_series_vals.p, c->d_series_off.p, c->d_series_cnt.p, c->d_series_base.p, d_status, s));
     return 0;
+}
+
+int32_t cramgpu_cigars_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_len, const int32_t* d_aln_start,
+                           const int32_t* d_bam_flags, const cramgpu_features* feats, int32_t* d_n_cigar, int64_t* d_cigar_off,
+                           uint32_t* d_cigar, int64_t cigar_cap, int32_t* d_aln_end, int32_t* d_status, void* stream) {
+    if (!c || n_reads < 0 || !d_read_len || !d_aln_start || !d_bam_flags || !feats || !feats->off || !d_n_cigar || !d_cigar_off ||
+        !d_cigar || cigar_cap < 0 || !d_aln_end || !d_status)
+        return fail(CRAMGPU_E_ARG, "cigars: bad argument");
+    if (n_reads > 0 && feats->cap > 0 && (!feats->op || !feats->pos || !feats->a || !feats->b))
+        return fail(CRAMGPU_E_ARG, "cigars: a feature column is missing");
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(c->d_scan_ws.reserve(feature_scan_ws_elems(n_reads)));
+    HIPCHK(launch_cigars(n_reads, d_read_len, d_aln_start, d_bam_flags, *feats, d_n_cigar, d_cigar_off, d_cigar, cigar_cap,
+                         d_aln_end, d_status, c->d_total.p, c->d_scan_ws.p, s));
+    return 0;
+}
+
+int32_t cramgpu_restore_mates_dev(cramgpu_ctx* c, int32_t n_reads, int32_t n_cont, const int32_t* d_cont_first,
+                                  const cramgpu_record_cols* cols, const int32_t* d_cont_ref_id, const int32_t* d_aln_start,
+                                  const int32_t* d_aln_end, int32_t* d_status, void* stream) {
+    if (!c || n_reads < 0 || n_cont < 1 || !d_cont_first || !cols || !d_cont_ref_id || !d_aln_start || !d_aln_end || !d_status)
+        return fail(CRAMGPU_E_ARG, "restore_mates: bad argument");
+    if (!cols->bam_flags || !cols->comp_flags || !cols->ref_id || !cols->mate_flags || !cols->mate_ref || !cols->mate_start ||
+        !cols->tlen || !cols->next_frag)
+        return fail(CRAMGPU_E_ARG, "restore_mates: a column is missing");
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(c->d_list.reserve((size_t)n_reads + 1));
+    HIPCHK(c->d_mate_prev.reserve((size_t)n_reads + 1));
+    HIPCHK(c->d_mate_serial.reserve((size_t)n_cont));
+    HIPCHK(launch_restore_mates(n_reads, n_cont, d_cont_first, *cols, d_cont_ref_id, d_aln_start, d_aln_end, c->d_list.p,
+                                c->d_mate_prev.p, c->d_mate_serial.p, d_status, s));
+    return 0;
+}
+
+int32_t cramgpu_bam_encode_dev(cramgpu_ctx* c, int32_t n_reads, const cramgpu_bam_cols* b, uint8_t* d_bam, int64_t bam_cap,
+                               int64_t* d_rec_off, int32_t* d_status, void* stream) {
+    if (!c || n_reads < 0 || !b || !d_bam || bam_cap < 0 || !d_rec_off || !d_status)
+        return fail(CRAMGPU_E_ARG, "bam_encode: bad argument");
+    if (!b->ref_id || !b->aln_start || !b->aln_end || !b->mapq || !b->bam_flags || !b->mate_flags || !b->mate_ref ||
+        !b->mate_start || !b->tlen || !b->read_len || !b->base_off || !b->bases || !b->quals || !b->n_cigar || !b->cigar_off ||
+        !b->cigar || (b->names && !b->name_off) || (b->tags && !b->tag_off) || (!b->names && b->name_base < 0))
+        return fail(CRAMGPU_E_ARG, "bam_encode: a column is missing");
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(c->d_counts.reserve((size_t)n_reads + 1));
+    HIPCHK(c->d_scan_ws.reserve(feature_scan_ws_elems(n_reads)));
+    HIPCHK(launch_bam_encode(n_reads, *b, d_bam, bam_cap, d_rec_off, d_status, c->d_counts.p, c->d_total.p, c->d_scan_ws.p, s));
+    return 0;
+}
+
+int32_t cramgpu_bam_decode_dev(cramgpu_ctx* c, int32_t n_reads, const uint8_t* d_bam, const int64_t* d_rec_off,
+                               const cramgpu_bam_out* o, int32_t* d_status, void* stream) {
+    if (!c || n_reads < 0 || !d_bam || !d_rec_off || !o || !d_status) return fail(CRAMGPU_E_ARG, "bam_decode: bad argument");
+    if (!o->ref_id || !o->aln_start || !o->mapq || !o->bam_flags || !o->mate_ref || !o->mate_start || !o->tlen || !o->read_len ||
+        !o->base_off || !o->bases || !o->quals || o->bases_cap < 0 || !o->n_cigar || !o->cigar_off || !o->cigar ||
+        o->cigar_cap < 0 || !o->aln_span || !o->rflags || !o->name_off || !o->name_len || !o->tag_off || !o->tag_len)
+        return fail(CRAMGPU_E_ARG, "bam_decode: an output column is missing");
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(c->d_scan_ws.reserve(feature_scan_ws_elems(n_reads)));
+    HIPCHK(launch_bam_decode(n_reads, d_bam, d_rec_off, *o, d_status, c->d_total.p, c->d_scan_ws.p, s));
+    return 0;
+}
+
+int64_t cramgpu_bam_index(const uint8_t* bam, int64_t len, int64_t* rec_off, int64_t cap) {
+    if (!bam || len < 0 || (cap > 0 && !rec_off)) return fail(CRAMGPU_E_ARG, "bam_index: bad argument");
+    int64_t at = 0, n = 0;
+    while (at < len) {  // Bam_OBA_Supplier.java:49-62
+        if (at + 4 > len) return fail(CRAMGPU_E_CORRUPT, "bam_index: the stripe ends inside a block size");
+        const int32_t bs = (int32_t)((uint32_t)bam[at] | (uint32_t)bam[at + 1] << 8 | (uint32_t)bam[at + 2] << 16 | (uint32_t)bam[at + 3] << 24);
+        if (bs < 32 || at + 4 + (int64_t)bs > len) return fail(CRAMGPU_E_CORRUPT, "bam_index: invalid record length");
+        if (n < cap) rec_off[n] = at;
+        n++;
+        at += 4 + (int64_t)bs;
+    }
+    if (n < cap) rec_off[n] = at;
+    return n;
 }
 
 int32_t cramgpu_assign_codes_dev(cramgpu_ctx* c, int32_t n_reads, const int32_t* d_read_cont, int32_t n_cont,

@@ -1,0 +1,571 @@
+// A — container assembly and BAM records for gfx950.
+//
+// Reference: CIGAR from read features — htsjdk!build/Cram2SamRecordFactory#getCigar2 L119-225 (bytecode only), the same
+// algorithm in source in src/main/java/htsjdk/samtools/cram/encoding/reader/ReadFeatureBuffer.java:180-294; mate
+// restoration — src/main/java/htsjdk/samtools/cram/build/CramNormalizer.java:82-105, :255-285, :455-470; the BAM record
+// layout — src/main/java/htsjdk/samtools/cram/encoding/reader/BAMRecordView.java:23-35, :106-119, :150-185, :229-241,
+// :360-415, driven as in ReaderToBAM.java:64-176 with the values of htsjdk!build/Cram2SamRecordFactory#create; stripes
+// of records — src/main/java/htsjdk/samtools/cram/paralell/Bam_OBA_Supplier.java:45-82, CramToBam_OBA_Function.java:64-75.
+//
+// Shape on the machine: the per-record decisions (CIGAR walk, mate chains, fixed fields) are a thread per record; the
+// bytes of a record (4-bit bases, scores, names, tags — a BAM record is ~280 bytes for a 150-base read) move with 16
+// lanes per record, 16 bases per lane and step, so that a wave writes four records' contiguous runs.  Offsets into the
+// stripe are prefix sums over record sizes (the tiled scan of the feature kernels).  HBM-bound byte shuffling:
+// algorithmic bytes = columns + bases + scores read once, records written once (and the reverse for the decoder).
+#include "internal.h"
+
+namespace {
+
+enum { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP_P = 6 };
+enum { BF_PAIRED = 1, BF_UNMAPPED = 4, BF_MATE_UNMAPPED = 8, BF_REVERSE = 16, BF_MATE_REVERSE = 32 };
+enum { MF_NEG_STRAND = 1, MF_UNMAPPED = 2 };
+
+struct __attribute__((packed)) U32u { uint32_t v; };
+struct __attribute__((packed)) U32x2u { uint32_t v[2]; };
+struct __attribute__((packed)) U32x4u { uint32_t v[4]; };
+
+// ---------------------------------------------------------------------------------------------------------------
+// CIGAR from features (ReadFeatureBuffer.java:180-294), a thread per record; WRITE=false counts.
+// ---------------------------------------------------------------------------------------------------------------
+struct CigarOut {
+    uint32_t* out;  // nullptr: count only
+    int32_t n;
+    __device__ __forceinline__ void emit(int32_t len, int op) {
+        if (out) out[n] = ((uint32_t)len << 4) | (uint32_t)op;
+        n++;
+    }
+};
+
+__device__ __forceinline__ int feature_cigar_op(uint8_t op, int32_t a, int32_t b, int32_t& len) {  // :213-257
+    switch (op) {
+        case 'I': len = b; return OP_I;
+        case 'S': len = b; return OP_S;
+        case 'H': len = a; return OP_H;
+        case 'i': len = 1; return OP_I;
+        case 'D': len = a; return OP_D;
+        case 'N': len = a; return OP_N;
+        case 'P': len = a; return OP_P;
+        case 'X':
+        case 'B': len = 1; return OP_M;
+        default: return -1;  // Q and the array operators carry no CIGAR element
+    }
+}
+
+__device__ int32_t cigar_walk(int32_t read_len, const cramgpu_features& F, int64_t f0, int64_t f1, uint32_t* out) {
+    CigarOut E{out, 0};
+    if (f1 == f0) {  // :182-185
+        E.emit(read_len, OP_M);
+        return E.n;
+    }
+    int last_op = OP_M;
+    int32_t last_len = 0, last_pos = 1;
+    for (int64_t k = f0; k < f1; k++) {
+        const int32_t rf_pos = F.pos[k];
+        const int32_t gap = rf_pos - (last_pos + last_len);  // :199-211
+        if (gap > 0) {
+            if (last_op != OP_M) {
+                E.emit(last_len, last_op);
+                last_pos += last_len;
+                last_len = gap;
+            } else {
+                last_len += gap;
+            }
+            last_op = OP_M;
+        }
+        int32_t rf_len = 0;
+        const int co = feature_cigar_op(F.op[k], F.a[k], F.b[k], rf_len);
+        if (co < 0) continue;
+        if (last_op != co) {  // :259-269
+            if (last_len > 0) E.emit(last_len, last_op);
+            last_op = co;
+            last_len = rf_len;
+            last_pos = rf_pos;
+        } else {
+            last_len += rf_len;
+        }
+        if (!(co == OP_M || co == OP_I || co == OP_S)) last_pos -= rf_len;  // :271-272
+    }
+    if (last_op != OP_M) {  // :275-286
+        E.emit(last_len, last_op);
+        if (read_len >= last_pos + last_len) E.emit(read_len - (last_len + last_pos) + 1, OP_M);
+    } else if (read_len > last_pos - 1) {
+        E.emit(read_len - last_pos + 1, OP_M);
+    }
+    if (E.n == 0) E.emit(read_len, OP_M);  // :288-291
+    return E.n;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void cigar_kernel(int32_t n, const int32_t* read_len, const int32_t* aln_start,
+                                                    const int32_t* bam_flags, cramgpu_features F, int32_t* n_cigar,
+                                                    const int64_t* cigar_off, uint32_t* cigar, int64_t cap, int32_t* aln_end,
+                                                    int32_t* status) {
+    const int32_t r = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (WRITE) {
+        const bool fits = cigar_off[n] <= cap;
+        if (r == 0) status[0] = fits ? 0 : CRAMGPU_E_INSUFFICIENT;
+        if (!fits) return;
+    }
+    if (r >= n) return;
+    const int64_t f0 = F.off[r], f1 = F.off[r + 1];
+    if (bam_flags[r] & BF_UNMAPPED) {  // SAMRecord.NO_ALIGNMENT_CIGAR
+        if (!WRITE) n_cigar[r] = 0, aln_end[r] = 0;
+        return;
+    }
+    if (WRITE) {
+        cigar_walk(read_len[r], F, f0, f1, cigar + cigar_off[r]);
+        return;
+    }
+    n_cigar[r] = cigar_walk(read_len[r], F, f0, f1, nullptr);
+    int32_t span = read_len[r];  // CramCompressionRecord#getAlignmentEnd
+    for (int64_t k = f0; k < f1; k++) {
+        const uint8_t o = F.op[k];
+        if (o == 'i')
+            span--;
+        else if (o == 'I' || o == 'S')
+            span -= F.b[k];
+        else if (o == 'D')
+            span += F.a[k];
+    }
+    aln_end[r] = aln_start[r] + span - 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Mate restoration (CramNormalizer.java:82-105, 255-285, 455-470)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t cont_of(const int32_t* cont_first, int32_t n_cont, int32_t r) {  // largest c: first[c] <= r
+    int32_t lo = 0, hi = n_cont - 1;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if (cont_first[mid] <= r)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+
+// link[r] = record the NF distance of r points at, or -1; nprev[j] = records that point at j; serial[c] = a record of
+// container c has more than one (the reference then lets the LAST chain that reaches it win: done by one thread)
+__global__ __launch_bounds__(256) void mates_link_kernel(int32_t n, int32_t n_cont, const int32_t* cont_first,
+                                                         cramgpu_record_cols C, const int32_t* cont_ref_id, int32_t* link,
+                                                         uint32_t* nprev, uint8_t* serial, int32_t* status) {
+    const int32_t r = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n) return;
+    const int32_t c = cont_of(cont_first, n_cont, r);
+    if (!(C.cont_multiref && C.cont_multiref[c])) C.ref_id[r] = cont_ref_id[c];
+    const int32_t bf = C.bam_flags[r], cf = C.comp_flags[r];
+    int32_t to = -1;
+    if (!(bf & BF_PAIRED) || (cf & CRAMGPU_CF_DETACHED)) {
+        C.next_frag[r] = -1;  // :85
+    } else if (cf & CRAMGPU_CF_HAS_MATE_DOWNSTREAM) {
+        const int64_t j = (int64_t)r + 1 + C.next_frag[r];
+        if (C.next_frag[r] < 0 || j >= cont_first[c + 1]) {
+            status[c] = CRAMGPU_E_JAVA_THROWS;  // records.get(...) throws; a negative distance links a record to itself or
+                                                // backwards, where restoreMateInfo's walk does not end: refused
+        } else {
+            to = (int32_t)j;
+            if (atomicAdd(&nprev[j], 1u) != 0u) serial[c] = 1;
+        }
+    }
+    link[r] = to;
+}
+
+struct MateCols {
+    const int32_t* bam_flags;
+    const int32_t* ref_id;
+    const int32_t* aln_start;
+    const int32_t* aln_end;
+    int32_t* mate_flags;
+    int32_t* mate_ref;
+    int32_t* mate_start;
+    int32_t* tlen;
+};
+__device__ __forceinline__ void set_next_mate(const MateCols& M, int32_t r, int32_t nx) {  // :278-285
+    const int32_t bf = M.bam_flags[nx];
+    int32_t ms = M.aln_start[nx];
+    const int32_t mr = M.ref_id[nx];
+    if (mr == -1) ms = 0;
+    M.mate_start[r] = ms;
+    M.mate_ref[r] = mr;
+    M.mate_flags[r] = (M.mate_flags[r] & ~(MF_UNMAPPED | MF_NEG_STRAND)) | ((bf & BF_UNMAPPED) ? MF_UNMAPPED : 0) |
+                      ((bf & BF_REVERSE) ? MF_NEG_STRAND : 0);
+}
+__device__ void restore_chain(const MateCols& M, const int32_t* link, int32_t head) {  // :255-276
+    int32_t cur = head;
+    while (link[cur] >= 0) {
+        set_next_mate(M, cur, link[cur]);
+        cur = link[cur];
+    }
+    set_next_mate(M, cur, head);
+    int32_t t = 0;  // :455-470
+    const int32_t b1 = M.bam_flags[head], b2 = M.bam_flags[cur];
+    if (!(b1 & BF_UNMAPPED) && !(b2 & BF_UNMAPPED) && M.ref_id[head] == M.ref_id[cur]) {
+        const int32_t p1 = (b1 & BF_REVERSE) ? M.aln_end[head] : M.aln_start[head];
+        const int32_t p2 = (b2 & BF_REVERSE) ? M.aln_end[cur] : M.aln_start[cur];
+        t = p2 - p1 + (p2 >= p1 ? 1 : -1);
+    }
+    M.tlen[head] = t;
+    M.tlen[cur] = -t;
+}
+__device__ __forceinline__ bool linked(const cramgpu_record_cols& C, int32_t r) {
+    return (C.bam_flags[r] & BF_PAIRED) && !(C.comp_flags[r] & CRAMGPU_CF_DETACHED);
+}
+
+__global__ __launch_bounds__(256) void mates_walk_kernel(int32_t n, int32_t n_cont, const int32_t* cont_first,
+                                                         cramgpu_record_cols C, const int32_t* aln_start, const int32_t* aln_end,
+                                                         const int32_t* link, const uint32_t* nprev, const uint8_t* serial,
+                                                         const int32_t* status) {
+    const int32_t r = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n) return;
+    const int32_t c = cont_of(cont_first, n_cont, r);
+    if (status[c] != 0) return;
+    const MateCols M{C.bam_flags, C.ref_id, aln_start, aln_end, C.mate_flags, C.mate_ref, C.mate_start, C.tlen};
+    if (serial[c]) {  // chains that share records: in record order, as the reference's loop
+        if (r != cont_first[c]) return;
+        for (int32_t i = cont_first[c]; i < cont_first[c + 1]; i++)
+            if (link[i] >= 0 && !(nprev[i] != 0u && linked(C, i))) restore_chain(M, link, i);
+        return;
+    }
+    // head of a chain: points at a record and is pointed at by none (a record that is not multi-fragment or is
+    // detached forgets who pointed at it: :84-89 runs after the pointer was set)
+    if (link[r] >= 0 && !(nprev[r] != 0u && linked(C, r))) restore_chain(M, link, r);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BAM records out
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t reg2bin(int64_t beg, int64_t end) {  // SAM specification §5.3
+    --end;
+    if (beg >> 14 == end >> 14) return (int32_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int32_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int32_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int32_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+__device__ __forceinline__ int32_t dec_digits(long long v) {
+    int32_t k = 1;
+    while (v >= 10) v /= 10, k++;
+    return k;
+}
+
+__global__ __launch_bounds__(256) void bam_size_kernel(int32_t n, cramgpu_bam_cols B, int32_t* sizes) {
+    const int32_t r = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n) return;
+    const int64_t ln = B.names ? B.name_off[r + 1] - B.name_off[r] : dec_digits(B.name_base + r);
+    const int64_t lt = B.tags ? B.tag_off[r + 1] - B.tag_off[r] : 0;
+    const int64_t L = B.read_len[r];
+    sizes[r] = (int32_t)(36 + ln + 1 + 4 * (int64_t)B.n_cigar[r] + (L + 1) / 2 + L + lt);
+}
+
+// BAMRecordView.java:360-415: code of a base, 0xFF = IllegalArgumentException
+__device__ __forceinline__ uint8_t nybble_of(uint32_t c) {
+    switch (c) {
+        case '=': return 0;
+        case 'A': case 'a': return 1;
+        case 'C': case 'c': return 2;
+        case 'M': case 'm': return 3;
+        case 'G': case 'g': return 4;
+        case 'R': case 'r': return 5;
+        case 'S': case 's': return 6;
+        case 'V': case 'v': return 7;
+        case 'T': case 't': return 8;
+        case 'W': case 'w': return 9;
+        case 'Y': case 'y': return 10;
+        case 'H': case 'h': return 11;
+        case 'K': case 'k': return 12;
+        case 'D': case 'd': return 13;
+        case 'B': case 'b': return 14;
+        case 'N': case 'n': case '.': return 15;
+        default: return 0xFF;
+    }
+}
+
+constexpr int kSub = 16;  // lanes per record
+
+__global__ __launch_bounds__(256) void bam_write_kernel(int32_t n, cramgpu_bam_cols B, uint8_t* bam, int64_t cap,
+                                                        const int64_t* rec_off, int32_t* status) {
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = nybble_of(threadIdx.x);
+    __syncthreads();
+    const int32_t r = (int32_t)(blockIdx.x * (blockDim.x / kSub) + threadIdx.x / kSub);
+    const int sl = (int)(threadIdx.x % kSub);
+    if (r >= n) return;
+    if (rec_off[n] > cap) {
+        if (sl == 0) status[r] = CRAMGPU_E_INSUFFICIENT;
+        return;
+    }
+    uint8_t* p = bam + rec_off[r];
+    const int32_t size = (int32_t)(rec_off[r + 1] - rec_off[r]);
+    const int32_t ln = B.names ? (int32_t)(B.name_off[r + 1] - B.name_off[r]) : dec_digits(B.name_base + r);
+    const int32_t lt = B.tags ? (int32_t)(B.tag_off[r + 1] - B.tag_off[r]) : 0;
+    const int32_t L = B.read_len[r], nc = B.n_cigar[r];
+    bool bad = ln + 1 > 255 || nc > 65535;
+    if (sl == 0) {  // the fixed part: BAMRecordView.java:23-35
+        const int32_t bf = B.bam_flags[r];
+        const int32_t rid = B.ref_id[r];
+        const bool placed = rid != -1;
+        const int32_t start = placed ? B.aln_start[r] : 0;
+        int32_t flags = bf & ~(BF_MATE_UNMAPPED | BF_MATE_REVERSE);
+        int32_t mref = -1, mstart = 0;
+        if (bf & BF_PAIRED) {
+            mref = B.mate_ref[r];
+            mstart = B.mate_start[r] > 0 ? B.mate_start[r] : 0;
+            const int32_t mf = B.mate_flags[r];
+            if (mf & MF_NEG_STRAND) flags |= BF_MATE_REVERSE;
+            if (mf & MF_UNMAPPED) flags |= BF_MATE_UNMAPPED;
+        }
+        int32_t bin = 0;
+        if (placed) {
+            const int64_t beg = (int64_t)start - 1;
+            int64_t end = (bf & BF_UNMAPPED) ? 0 : B.aln_end[r];
+            if (end <= 0 || end <= beg) end = beg + 1;
+            bin = reg2bin(beg, end);
+        }
+        U32u* w = reinterpret_cast<U32u*>(p);
+        w[0].v = (uint32_t)(size - 4);
+        w[1].v = (uint32_t)rid;
+        w[2].v = (uint32_t)(start - 1);
+        w[3].v = (uint32_t)((ln + 1) & 255) | (uint32_t)(placed ? B.mapq[r] : 0) << 8 | (uint32_t)(bin & 0xFFFF) << 16;
+        w[4].v = (uint32_t)(nc & 0xFFFF) | (uint32_t)(flags & 0xFFFF) << 16;
+        w[5].v = (uint32_t)L;
+        w[6].v = (uint32_t)mref;
+        w[7].v = (uint32_t)(mstart - 1);
+        w[8].v = (uint32_t)B.tlen[r];
+        p[36 + ln] = 0;
+    }
+    if (B.names) {
+        const uint8_t* nm = B.names + B.name_off[r];
+        for (int32_t i = sl; i < ln; i += kSub) p[36 + i] = nm[i];
+    } else {
+        long long v = B.name_base + r;  // digit sl from the right
+        for (int32_t i = 0; i < sl && i < ln; i++) v /= 10;
+        if (sl < ln) p[36 + ln - 1 - sl] = (uint8_t)('0' + v % 10);
+        for (int32_t i = sl + kSub; i < ln; i += kSub) {  // more than 16 digits
+            for (int32_t q = 0; q < kSub; q++) v /= 10;
+            p[36 + ln - 1 - i] = (uint8_t)('0' + v % 10);
+        }
+    }
+    uint8_t* q = p + 36 + ln + 1;
+    {
+        const uint32_t* cg = B.cigar + B.cigar_off[r];
+        U32u* w = reinterpret_cast<U32u*>(q);
+        for (int32_t k = sl; k < nc; k += kSub) w[k].v = cg[k];
+    }
+    q += 4 * (int64_t)nc;
+    const int64_t bo = B.base_off[r];
+    const int64_t n_bases = B.base_off[n];
+    const uint8_t* bs = B.bases + bo;
+    for (int32_t u = sl * 16; u < L; u += kSub * 16) {  // BAMRecordView.java:150-166
+        uint32_t w[4];
+        if (bo + u + 16 <= n_bases) {
+            const U32x4u t = *reinterpret_cast<const U32x4u*>(bs + u);
+            w[0] = t.v[0], w[1] = t.v[1], w[2] = t.v[2], w[3] = t.v[3];
+        } else {
+            w[0] = w[1] = w[2] = w[3] = 0;
+            for (int32_t j = 0; u + j < L; j++) w[j >> 2] |= (uint32_t)bs[u + j] << (8 * (j & 3));
+        }
+        const int32_t nb = L - u < 16 ? L - u : 16;
+        uint32_t o[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint32_t c = lut[(w[j >> 2] >> (8 * (j & 3))) & 255u];
+            if (j >= nb)
+                c = 0;
+            else if (c == 0xFFu)
+                bad = true, c = 15;
+            o[j >> 3] |= c << (8 * ((j & 7) >> 1) + ((j & 1) ? 0 : 4));
+        }
+        uint8_t* d = q + (u >> 1);
+        if (nb == 16) {
+            U32x2u t;
+            t.v[0] = o[0], t.v[1] = o[1];
+            *reinterpret_cast<U32x2u*>(d) = t;
+        } else {
+            for (int32_t j = 0; j < (nb + 1) / 2; j++) d[j] = (uint8_t)(o[j >> 2] >> (8 * (j & 3)));
+        }
+    }
+    q += (L + 1) / 2;
+    const bool has_q = !(B.qual_status && B.qual_status[r] == 1);
+    const uint8_t* qs = B.quals + bo;
+    for (int32_t u = sl * 16; u < L; u += kSub * 16) {  // :172-185
+        if (u + 16 <= L && (!has_q || bo + u + 16 <= n_bases)) {
+            U32x4u t;
+            if (has_q)
+                t = *reinterpret_cast<const U32x4u*>(qs + u);
+            else
+                t.v[0] = t.v[1] = t.v[2] = t.v[3] = 0xFFFFFFFFu;
+            *reinterpret_cast<U32x4u*>(q + u) = t;
+        } else {
+            for (int32_t j = u; j < L && j < u + 16; j++) q[j] = has_q ? qs[j] : (uint8_t)0xFF;
+        }
+    }
+    q += L;
+    if (lt) {
+        const uint8_t* tg = B.tags + B.tag_off[r];
+        for (int32_t i = sl; i < lt; i += kSub) q[i] = tg[i];
+    }
+    if (bad) status[r] = CRAMGPU_E_JAVA_THROWS;  // status was zeroed before the launch; every lane stores the same code
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BAM records in
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t ld32(const uint8_t* p) { return (int32_t)reinterpret_cast<const U32u*>(p)->v; }
+
+__global__ __launch_bounds__(256) void bam_head_kernel(int32_t n, const uint8_t* bam, const int64_t* rec_off, cramgpu_bam_out O,
+                                                       int32_t* status) {
+    const int32_t r = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n) return;
+    const uint8_t* p = bam + rec_off[r];
+    const int64_t size = rec_off[r + 1] - rec_off[r];
+    int32_t ln = 0, nc = 0, L = 0;
+    int64_t need = 0;
+    bool ok = size >= 36;
+    if (ok) {
+        ln = p[12], nc = (int32_t)p[16] | (int32_t)p[17] << 8, L = ld32(p + 20);
+        need = 36 + (int64_t)ln + 4 * (int64_t)nc + ((int64_t)L + 1) / 2 + L;
+        ok = L >= 0 && need <= size && (int64_t)ld32(p) + 4 == size;
+    }
+    if (!ok) {
+        status[r] = CRAMGPU_E_CORRUPT;
+        O.ref_id[r] = -1, O.aln_start[r] = 0, O.mapq[r] = 0, O.bam_flags[r] = 0, O.mate_ref[r] = -1, O.mate_start[r] = 0;
+        O.tlen[r] = 0, O.read_len[r] = 0, O.n_cigar[r] = 0, O.aln_span[r] = 0, O.rflags[r] = CRAMGPU_RF_SKIP;
+        O.name_off[r] = 0, O.name_len[r] = 0, O.tag_off[r] = 0, O.tag_len[r] = 0;
+        return;
+    }
+    status[r] = 0;
+    const int32_t flags = (int32_t)p[18] | (int32_t)p[19] << 8;
+    O.ref_id[r] = ld32(p + 4);
+    O.aln_start[r] = ld32(p + 8) + 1;
+    O.mapq[r] = p[13];
+    O.bam_flags[r] = flags;
+    O.read_len[r] = L;
+    O.mate_ref[r] = ld32(p + 24);
+    O.mate_start[r] = ld32(p + 28) + 1;
+    O.tlen[r] = ld32(p + 32);
+    O.n_cigar[r] = nc;
+    O.name_off[r] = rec_off[r] + 36;
+    O.name_len[r] = ln > 0 ? ln - 1 : 0;
+    O.tag_off[r] = rec_off[r] + need;
+    O.tag_len[r] = (int32_t)(size - need);
+    int32_t span = 0;
+    const uint8_t* q = p + 36 + ln;
+    for (int32_t k = 0; k < nc; k++) {  // BAMRecordView.java:589-621
+        const uint32_t e = (uint32_t)ld32(q + 4 * k);
+        const uint32_t o = e & 15u;
+        if (o == 0 || o == 2 || o == 3 || o == 7 || o == 8) span += (int32_t)(e >> 4);
+    }
+    O.aln_span[r] = span;
+    const uint8_t* sc = q + 4 * (int64_t)nc + (L + 1) / 2;
+    O.rflags[r] = (uint8_t)(((flags & BF_UNMAPPED) ? CRAMGPU_RF_UNMAPPED : 0) | ((L == 0 || sc[0] == 0xFF) ? CRAMGPU_RF_NULL_QUALS : 0) |
+                            (L == 0 ? CRAMGPU_RF_NO_BASES : 0));
+}
+
+__global__ __launch_bounds__(256) void bam_body_kernel(int32_t n, const uint8_t* bam, const int64_t* rec_off, cramgpu_bam_out O,
+                                                       int32_t* status) {
+    __shared__ uint8_t dec[16];
+    if (threadIdx.x < 16) dec[threadIdx.x] = (uint8_t)"=ACMGRSVTWYHKDBN"[threadIdx.x];
+    __syncthreads();
+    const int32_t r = (int32_t)(blockIdx.x * (blockDim.x / kSub) + threadIdx.x / kSub);
+    const int sl = (int)(threadIdx.x % kSub);
+    if (r >= n) return;
+    if (O.base_off[n] > O.bases_cap || O.cigar_off[n] > O.cigar_cap) {
+        if (sl == 0) status[r] = CRAMGPU_E_INSUFFICIENT;
+        return;
+    }
+    if (status[r] != 0) return;
+    const uint8_t* p = bam + rec_off[r];
+    const int32_t ln = p[12], nc = O.n_cigar[r], L = O.read_len[r];
+    const uint8_t* q = p + 36 + ln;
+    uint32_t* cg = O.cigar + O.cigar_off[r];
+    for (int32_t k = sl; k < nc; k += kSub) cg[k] = (uint32_t)ld32(q + 4 * k);
+    q += 4 * (int64_t)nc;
+    const int64_t bo = O.base_off[r];
+    const int64_t size_left = rec_off[r + 1] - (rec_off[r] + 36 + ln + 4 * (int64_t)nc);  // bytes from q to the record's end
+    uint8_t* bd = O.bases + bo;
+    for (int32_t u = sl * 16; u < L; u += kSub * 16) {
+        const int32_t nb = L - u < 16 ? L - u : 16;
+        uint32_t w[2] = {0u, 0u};
+        if ((u >> 1) + 8 <= size_left) {
+            const U32x2u t = *reinterpret_cast<const U32x2u*>(q + (u >> 1));
+            w[0] = t.v[0], w[1] = t.v[1];
+        } else {
+            for (int32_t j = 0; j < (nb + 1) / 2; j++) w[j >> 2] |= (uint32_t)q[(u >> 1) + j] << (8 * (j & 3));
+        }
+        uint32_t o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t byte = (w[j >> 3] >> (8 * ((j & 7) >> 1))) & 255u;
+            const uint32_t c = dec[(j & 1) ? (byte & 15u) : (byte >> 4)];
+            o[j >> 2] |= c << (8 * (j & 3));
+        }
+        if (nb == 16 && bo + u + 16 <= O.bases_cap) {
+            U32x4u t;
+            t.v[0] = o[0], t.v[1] = o[1], t.v[2] = o[2], t.v[3] = o[3];
+            *reinterpret_cast<U32x4u*>(bd + u) = t;
+        } else {
+            for (int32_t j = 0; j < nb; j++) bd[u + j] = (uint8_t)(o[j >> 2] >> (8 * (j & 3)));
+        }
+    }
+    q += (L + 1) / 2;
+    uint8_t* qd = O.quals + bo;
+    for (int32_t u = sl * 16; u < L; u += kSub * 16) {
+        if (u + 16 <= L) {
+            *reinterpret_cast<U32x4u*>(qd + u) = *reinterpret_cast<const U32x4u*>(q + u);
+        } else {
+            for (int32_t j = u; j < L; j++) qd[j] = q[j];
+        }
+    }
+}
+
+inline dim3 grid1(int64_t n, int per_block) { return dim3((unsigned)((n + per_block - 1) / per_block > 0 ? (n + per_block - 1) / per_block : 1)); }
+
+}  // namespace
+
+hipError_t launch_cigars(int32_t n, const int32_t* read_len, const int32_t* aln_start, const int32_t* bam_flags,
+                         const cramgpu_features& f, int32_t* n_cigar, int64_t* cigar_off, uint32_t* cigar, int64_t cap,
+                         int32_t* aln_end, int32_t* status, int64_t* d_total, int64_t* d_scan_ws, hipStream_t s) {
+    hipLaunchKernelGGL(cigar_kernel<false>, grid1(n, 256), dim3(256), 0, s, n, read_len, aln_start, bam_flags, f, n_cigar,
+                       (const int64_t*)nullptr, (uint32_t*)nullptr, cap, aln_end, status);
+    hipError_t e = launch_feature_scan(n, n_cigar, cigar_off, d_total, d_scan_ws, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cigar_kernel<true>, grid1(n, 256), dim3(256), 0, s, n, read_len, aln_start, bam_flags, f, n_cigar,
+                       (const int64_t*)cigar_off, cigar, cap, aln_end, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_restore_mates(int32_t n, int32_t n_cont, const int32_t* cont_first, const cramgpu_record_cols& c,
+                                const int32_t* cont_ref_id, const int32_t* aln_start, const int32_t* aln_end, int32_t* link,
+                                uint32_t* nprev, uint8_t* serial, int32_t* status, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(nprev, 0, (size_t)(n > 0 ? n : 1) * sizeof(uint32_t), s);
+    if (e == hipSuccess) e = hipMemsetAsync(serial, 0, (size_t)n_cont, s);
+    if (e == hipSuccess) e = hipMemsetAsync(status, 0, (size_t)n_cont * sizeof(int32_t), s);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(mates_link_kernel, grid1(n, 256), dim3(256), 0, s, n, n_cont, cont_first, c, cont_ref_id, link, nprev,
+                       serial, status);
+    hipLaunchKernelGGL(mates_walk_kernel, grid1(n, 256), dim3(256), 0, s, n, n_cont, cont_first, c, aln_start, aln_end,
+                       (const int32_t*)link, (const uint32_t*)nprev, (const uint8_t*)serial, (const int32_t*)status);
+    return hipGetLastError();
+}
+
+hipError_t launch_bam_encode(int32_t n, const cramgpu_bam_cols& b, uint8_t* bam, int64_t cap, int64_t* rec_off, int32_t* status,
+                             int32_t* d_sizes, int64_t* d_total, int64_t* d_scan_ws, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(bam_size_kernel, grid1(n, 256), dim3(256), 0, s, n, b, d_sizes);
+    hipError_t e = launch_feature_scan(n, d_sizes, rec_off, d_total, d_scan_ws, s);
+    if (e == hipSuccess && n > 0) e = hipMemsetAsync(status, 0, (size_t)n * sizeof(int32_t), s);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(bam_write_kernel, grid1(n, 256 / kSub), dim3(256), 0, s, n, b, bam, cap, (const int64_t*)rec_off, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_bam_decode(int32_t n, const uint8_t* bam, const int64_t* rec_off, const cramgpu_bam_out& o, int32_t* status,
+                             int64_t* d_total, int64_t* d_scan_ws, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(bam_head_kernel, grid1(n, 256), dim3(256), 0, s, n, bam, rec_off, o, status);
+    hipError_t e = launch_feature_scan(n, o.read_len, o.base_off, d_total, d_scan_ws, s);
+    if (e == hipSuccess) e = launch_feature_scan(n, o.n_cigar, o.cigar_off, d_total, d_scan_ws, s);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(bam_body_kernel, grid1(n, 256 / kSub), dim3(256), 0, s, n, bam, rec_off, o, status);
+    return hipGetLastError();
+}

@@ -90,3 +90,15 @@ hipError_t launch_lossy_quals(const cramgpu_reads& r, const uint8_t* ref, const 
 hipError_t launch_merge_quality(int32_t n_reads, const int32_t* read_len, const int64_t* base_off, const uint8_t* scores,
                                 const uint8_t* force, const int32_t* qstatus, cramgpu_features in, cramgpu_features out,
                                 int32_t* d_counts, bool write_pass, const int64_t* d_total_guard, hipStream_t s);
+
+// container assembly / BAM records (bam.hip)
+hipError_t launch_cigars(int32_t n, const int32_t* read_len, const int32_t* aln_start, const int32_t* bam_flags,
+                         const cramgpu_features& f, int32_t* n_cigar, int64_t* cigar_off, uint32_t* cigar, int64_t cap,
+                         int32_t* aln_end, int32_t* status, int64_t* d_total, int64_t* d_scan_ws, hipStream_t s);
+hipError_t launch_restore_mates(int32_t n, int32_t n_cont, const int32_t* cont_first, const cramgpu_record_cols& c,
+                                const int32_t* cont_ref_id, const int32_t* aln_start, const int32_t* aln_end, int32_t* link,
+                                uint32_t* nprev, uint8_t* serial, int32_t* status, hipStream_t s);
+hipError_t launch_bam_encode(int32_t n, const cramgpu_bam_cols& b, uint8_t* bam, int64_t cap, int64_t* rec_off, int32_t* status,
+                             int32_t* d_sizes, int64_t* d_total, int64_t* d_scan_ws, hipStream_t s);
+hipError_t launch_bam_decode(int32_t n, const uint8_t* bam, const int64_t* rec_off, const cramgpu_bam_out& o, int32_t* status,
+                             int64_t* d_total, int64_t* d_scan_ws, hipStream_t s);

@@ -821,7 +821,7 @@ __global__ __launch_bounds__(kTile) void series_read_kernel(RArgs A) {
             A.c.mate_start[r] = det && ok ? VAL(CRAMGPU_DS_NP, i_det) : 0;
             A.c.tlen[r] = det && ok ? VAL(CRAMGPU_DS_TS, i_det) : 0;
             A.c.next_frag[r] = down && ok ? VAL(CRAMGPU_DS_NF, i_down) : 0;
-            A.o.mapq[r] = mapped && ok ? (uint8_t)VAL(CRAMGPU_DS_MQ, i_map) : (uint8_t)255;
+            A.o.mapq[r] = mapped && ok ? (uint8_t)VAL(CRAMGPU_DS_MQ, i_map) : (uint8_t)0;  // NO_MAPPING_QUALITY
             A.o.base_off[r] = boff;
             if (A.o.rflags)
                 A.o.rflags[r] = (uint8_t)(((bf & CRAMGPU_BF_SEGMENT_UNMAPPED) ? CRAMGPU_RF_UNMAPPED : 0) |

@@ -349,7 +349,7 @@ int32_t cramgpu_write_series_dev(cramgpu_ctx* ctx, const cramgpu_reads* reads, c
 typedef struct {
     int32_t* read_len;   /* [n_reads] RL */
     int32_t* aln_start;  /* [n_reads] AP (deltas summed from cont_ap_base) */
-    uint8_t* mapq;       /* [n_reads] MQ (255 for unmapped records, as ReaderToBAM.java:157) */
+    uint8_t* mapq;       /* [n_reads] MQ (0 = SAMRecord.NO_MAPPING_QUALITY for unmapped records, ReaderToBAM.java:157) */
     int64_t* base_off;   /* [n_reads + 1] offset of record r in bases / quals: records back to back */
     uint8_t* bases;      /* bases of unmapped records (BA); mapped records are left for cramgpu_restore_bases_dev */
     uint8_t* quals;      /* the QS array of force-preserved records, 0xFF elsewhere (what cramgpu_restore_quals_dev expects) */
@@ -374,6 +374,120 @@ int32_t cramgpu_read_series_dev(cramgpu_ctx* ctx, int32_t n_reads, int32_t n_con
                                 const uint8_t* d_arena, const int64_t* d_series_off, const int32_t* d_series_len,
                                 int64_t series_bytes, const cramgpu_record_cols* cols, const cramgpu_read_out* out,
                                 const cramgpu_features* feats, int32_t* d_status, void* stream);
+
+/* =====================================================================================================
+ * Container assembly and BAM records: what stands between the reader's columns and the
+ * BAM stripe of src/main/java/htsjdk/samtools/cram/paralell/CramToBam_OBA_Function.java:64-75 (normalize, then per record
+ * Cram2SamRecordFactory#create + BAMRecordCodec#encode), and between the BAM stripe of Bam_OBA_Supplier.java:45-82 and
+ * the columns K3 takes.  BGZF (de)compression stays with the host.
+ * ===================================================================================================== */
+
+/* CIGAR of every mapped record from its read features — htsjdk!build/Cram2SamRecordFactory#getCigar2 (L119-225); the
+ * reference tree states the algorithm in source, src/main/java/htsjdk/samtools/cram/encoding/reader/ReadFeatureBuffer.java
+ * :180-294 (#getCigar) — and the record's alignment end (htsjdk!structure/CramCompressionRecord#getAlignmentEnd:
+ * start + readLength - |I| - |i| - |S| + |D| - 1).  Elements are BAM words (len << 4 | op).  Unmapped records
+ * (d_bam_flags & 4) get no element ("*") and end 0.
+ * d_n_cigar[n_reads], d_cigar_off[n_reads + 1], d_aln_end[n_reads] are always filled; d_cigar only when the total fits
+ * cigar_cap.  d_status[0] = 0 or CRAMGPU_E_INSUFFICIENT (d_cigar_off[n_reads] = the capacity needed).
+ * Stream-ordered, does not synchronise. */
+int32_t cramgpu_cigars_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32_t* d_read_len, const int32_t* d_aln_start,
+                           const int32_t* d_bam_flags, const cramgpu_features* feats, int32_t* d_n_cigar, int64_t* d_cigar_off,
+                           uint32_t* d_cigar, int64_t cigar_cap, int32_t* d_aln_end, int32_t* d_status, void* stream);
+
+/* Mate restoration of CramNormalizer#normalize — src/main/java/htsjdk/samtools/cram/build/CramNormalizer.java:82-105
+ * (pairing by NF), :255-285 (restoreMateInfo / setNextMate), :455-470 (computeInsertSize) — for every container of the
+ * batch.  Reads cols->bam_flags, comp_flags, next_frag, d_aln_start, d_aln_end (cramgpu_cigars_dev); writes
+ * cols->mate_flags (bits 1 = mate on the negative strand, 2 = mate unmapped), mate_ref, mate_start, tlen of the chained
+ * records, next_frag = -1 for records that are not multi-fragment or are detached (:85), and cols->ref_id[r] =
+ * d_cont_ref_id[c] for every record of a container that is not multi-reference (so that ref_id is the record's
+ * sequence id afterwards in every container).  d_status[n_cont]: 0, or CRAMGPU_E_JAVA_THROWS for a container with a
+ * next-fragment distance that points outside it (records.get throws) or is negative (a self / backward link, on which
+ * restoreMateInfo's walk does not end); the mate columns of its records are left as they were, its next_frag column is
+ * unspecified (the reference's call ends in the exception half way through the container).
+ * Stream-ordered, does not synchronise. */
+int32_t cramgpu_restore_mates_dev(cramgpu_ctx* ctx, int32_t n_reads, int32_t n_cont, const int32_t* d_cont_first,
+                                  const cramgpu_record_cols* cols, const int32_t* d_cont_ref_id, const int32_t* d_aln_start,
+                                  const int32_t* d_aln_end, int32_t* d_status, void* stream);
+
+/* The columns of one batch of records as BAMRecordCodec#encode needs them (device arrays, [n_reads] unless noted). */
+typedef struct {
+    const int32_t* ref_id;      /* sequence id of the record (-1 = unplaced) */
+    const int32_t* aln_start;   /* 1-based */
+    const int32_t* aln_end;     /* 1-based inclusive (cramgpu_cigars_dev); index bin only */
+    const uint8_t* mapq;
+    const int32_t* bam_flags;   /* BF; the mate-unmapped / mate-strand bits are taken from mate_flags */
+    const int32_t* mate_flags;
+    const int32_t* mate_ref;
+    const int32_t* mate_start;
+    const int32_t* tlen;
+    const int32_t* read_len;
+    const int64_t* base_off;    /* [n_reads + 1] */
+    const uint8_t* bases;       /* ASCII, restored */
+    const uint8_t* quals;       /* restored scores */
+    const int32_t* qual_status; /* d_status of cramgpu_restore_quals_dev (1 = no scores: 0xFF x length), or NULL */
+    const int32_t* n_cigar;
+    const int64_t* cigar_off;
+    const uint32_t* cigar;
+    const uint8_t* names;       /* read names without terminator, or NULL: the decimal of name_base + r, the name */
+    const int64_t* name_off;    /*   CramNormalizer.java:108-117 gives a record that carries none ([n_reads + 1]) */
+    int64_t name_base;
+    const uint8_t* tags;        /* BAM-encoded tag bytes per record, or NULL */
+    const int64_t* tag_off;     /* [n_reads + 1] */
+} cramgpu_bam_cols;
+
+/* One BAM alignment record per record, back to back (block_size first) — the layout of
+ * src/main/java/htsjdk/samtools/cram/encoding/reader/BAMRecordView.java:23-35, :106-119, :150-185, :229-241 with the
+ * values htsjdk!build/Cram2SamRecordFactory#create sets (unplaced: start 0, mapping quality 0; unpaired: mate reference
+ * -1, mate start 0) and the index bin of the SAM specification §5.3 (reg2bin; 0 for an unplaced record).
+ * d_rec_off[n_reads + 1] always; bytes only when they fit bam_cap.  d_status[n_reads]: 0, CRAMGPU_E_JAVA_THROWS (a base
+ * outside "=ACMGRSVTWYHKDBN." of either case: BAMRecordView.java:412 throws; a name above 254 bytes; more than 65535
+ * CIGAR elements) or CRAMGPU_E_INSUFFICIENT for every record when bam_cap is too small (d_rec_off[n_reads] = need).
+ * Stream-ordered, does not synchronise. */
+int32_t cramgpu_bam_encode_dev(cramgpu_ctx* ctx, int32_t n_reads, const cramgpu_bam_cols* cols, uint8_t* d_bam, int64_t bam_cap,
+                               int64_t* d_rec_off, int32_t* d_status, void* stream);
+
+/* What cramgpu_bam_decode_dev fills (device arrays, [n_reads] unless noted): the columns of cramgpu_reads and
+ * cramgpu_record_cols a BAM record carries. */
+typedef struct {
+    int32_t* ref_id;
+    int32_t* aln_start;   /* 1-based (pos + 1) */
+    uint8_t* mapq;
+    int32_t* bam_flags;
+    int32_t* mate_ref;
+    int32_t* mate_start;  /* 1-based */
+    int32_t* tlen;
+    int32_t* read_len;
+    int64_t* base_off;    /* [n_reads + 1] */
+    uint8_t* bases;       /* ASCII from the 4-bit codes ("=ACMGRSVTWYHKDBN") */
+    uint8_t* quals;
+    int64_t bases_cap;
+    int32_t* n_cigar;
+    int64_t* cigar_off;   /* [n_reads + 1] */
+    uint32_t* cigar;
+    int64_t cigar_cap;
+    int32_t* aln_span;    /* reference bases the CIGAR consumes (M D N = X; BAMRecordView.java:589-621) */
+    uint8_t* rflags;      /* CRAMGPU_RF_UNMAPPED (flag 4), CRAMGPU_RF_NULL_QUALS (no scores: first byte 0xFF),
+                             CRAMGPU_RF_NO_BASES (l_seq 0), CRAMGPU_RF_SKIP (malformed record) */
+    int64_t* name_off;    /* where the read name lies in the stripe */
+    int32_t* name_len;    /* without the terminator */
+    int64_t* tag_off;     /* where the tag bytes lie in the stripe */
+    int32_t* tag_len;
+} cramgpu_bam_out;
+
+/* BAMRecordCodec#decode over a stripe of BAM records (src/main/java/htsjdk/samtools/cram/paralell/Bam_OBA_Supplier.java
+ * :45-82 builds it: block_size + record, up to 10 000 records of one reference).  d_rec_off[n_reads + 1] = record
+ * offsets in d_bam (the supplier reads every block_size while it builds the stripe, :49-51; cramgpu_bam_index is the
+ * same walk for a host that did not keep them).  d_status[n_reads]: 0, CRAMGPU_E_CORRUPT (fields overrun the record)
+ * or CRAMGPU_E_INSUFFICIENT for every record when bases_cap / cigar_cap are too small (base_off / cigar_off [n_reads]
+ * hold the needs).  Strings stay in the stripe: name_off / tag_off point at them.
+ * Stream-ordered, does not synchronise. */
+int32_t cramgpu_bam_decode_dev(cramgpu_ctx* ctx, int32_t n_reads, const uint8_t* d_bam, const int64_t* d_rec_off,
+                               const cramgpu_bam_out* out, int32_t* d_status, void* stream);
+
+/* Host: record offsets of a stripe (block sizes walked as Bam_OBA_Supplier.java:49-62 does).  rec_off[cap]; returns the
+ * number of records (rec_off[n] = stripe length when n < cap) or CRAMGPU_E_CORRUPT (a block size below 32 or past the
+ * end: SAMFormatException "Invalid record length"). */
+int64_t cramgpu_bam_index(const uint8_t* bam, int64_t len, int64_t* rec_off, int64_t cap);
 
 /* Q1 result — htsjdk!lossy/PreservationPolicy as a POD (parsed on the host by the caller, see
  * src/main/java/htsjdk/samtools/cram/lossy/QualityScorePreservation.java:167-256). */

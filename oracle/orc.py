@@ -37,7 +37,7 @@ class Policy(ctypes.Structure):
 def build():
     """Compile liboracle.so with gcc (idempotent)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rans4x8.c", "records.c", "series.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("rans4x8.c", "records.c", "series.c", "bam.c")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
     return so
@@ -444,3 +444,112 @@ def read_series(streams, n_reads, multiref=False, ap_base=0, ap_delta=True):
         raise RuntimeError("oracle read_series error %d" % r)
     res["n_feat"] = int(r)
     return res
+
+
+# ---------------------------------------------------------------- container assembly / BAM records (oracle/bam.c)
+def _a(x, dt):
+    return np.ascontiguousarray(x, dt)
+
+
+def cigars(read_len, aln_start, bam_flags, feats, cigar_cap=None):
+    """Cram2SamRecordFactory#getCigar2 (algorithm: ReadFeatureBuffer.java:180-294) for every record.
+    -> dict n_cigar, cigar_off[n + 1], cigar (uint32), aln_end, total."""
+    n = len(read_len)
+    rl, st, bf = _a(read_len, np.int32), _a(aln_start, np.int32), _a(bam_flags, np.int32)
+    op, pos, fa, fb = _a(feats["op"], np.uint8), _a(feats["pos"], np.int32), _a(feats["a"], np.int32), _a(feats["b"], np.int32)
+    off = _a(feats["off"], np.int64)
+    cap = int(cigar_cap) if cigar_cap is not None else n + 2 * len(op) + 1
+    res = dict(n_cigar=np.zeros(n, np.int32), cigar_off=np.zeros(n + 1, np.int64), cigar=np.zeros(max(cap, 1), np.uint32),
+               aln_end=np.zeros(n, np.int32))
+    f = lib().orc_cigars
+    f.restype = ctypes.c_int64
+    res["total"] = int(f(ctypes.c_int32(n), _p(rl), _p(st), _p(bf), _p(op), _p(pos), _p(fa), _p(fb), _p(off), _p(res["n_cigar"]),
+                         _p(res["cigar_off"]), _p(res["cigar"]), ctypes.c_int64(cap), _p(res["aln_end"])))
+    return res
+
+
+def restore_mates(cont_first, cols, ref_id, aln_start, aln_end):
+    """CramNormalizer.java:82-105, 255-285, 455-470 per container.  cols: dict of int32 arrays (copied); ref_id per record.
+    -> (dict of the updated columns next_frag / mate_flags / mate_ref / mate_start / tlen, status per container)."""
+    out = {k: _a(cols[k], np.int32).copy() for k in ("next_frag", "mate_flags", "mate_ref", "mate_start", "tlen")}
+    bf, cf, rid = _a(cols["bam_flags"], np.int32), _a(cols["comp_flags"], np.int32), _a(ref_id, np.int32)
+    st, en = _a(aln_start, np.int32), _a(aln_end, np.int32)
+    status = np.zeros(len(cont_first) - 1, np.int32)
+    for c in range(len(cont_first) - 1):
+        keep = {k: v.copy() for k, v in out.items()}
+        status[c] = lib().orc_restore_mates(ctypes.c_int32(int(cont_first[c])), ctypes.c_int32(int(cont_first[c + 1])), _p(bf), _p(cf),
+                                            _p(rid), _p(st), _p(en), _p(out["next_frag"]), _p(out["mate_flags"]), _p(out["mate_ref"]),
+                                            _p(out["mate_start"]), _p(out["tlen"]))
+        if status[c] != 0:  # the reference threw: the mate columns stay as they were (next_frag = -1 of :85 is kept)
+            lo, hi = int(cont_first[c]), int(cont_first[c + 1])
+            for k in ("mate_flags", "mate_ref", "mate_start", "tlen"):
+                out[k][lo:hi] = keep[k][lo:hi]
+    return out, status
+
+
+def bam_encode(ref_id, aln_start, aln_end, mapq, bam_flags, mate_flags, mate_ref, mate_start, tlen, read_len, base_off, bases,
+               quals, has_quals, n_cigar, cigar_off, cigar, names=None, name_off=None, name_base=0, tags=None, tag_off=None,
+               cap=None):
+    """One BAM record per record (layout: BAMRecordView.java:23-35 ...).  -> (bytes, rec_off[n + 1], status[n])."""
+    n = len(read_len)
+    i32 = lambda x: _a(x, np.int32)
+    rl = i32(read_len)
+    if cap is None:
+        cap = int(64 * n + 2 * int(rl.sum()) + 4 * len(cigar) + (len(names) if names is not None else 24 * n) +
+                  (len(tags) if tags is not None else 0) + 64)
+    out = np.zeros(cap, np.uint8)
+    rec_off = np.zeros(n + 1, np.int64)
+    status = np.zeros(max(n, 1), np.int32)
+    f = lib().orc_bam_encode
+    f.restype = ctypes.c_int64
+    nm = _a(names, np.uint8) if names is not None else None
+    tg = _a(tags, np.uint8) if tags is not None else None
+    no = _a(name_off, np.int64) if name_off is not None else None
+    to = _a(tag_off, np.int64) if tag_off is not None else None
+    nul = ctypes.c_void_p(None)
+    tot = int(f(ctypes.c_int32(n), _p(i32(ref_id)), _p(i32(aln_start)), _p(i32(aln_end)), _p(_a(mapq, np.uint8)), _p(i32(bam_flags)),
+                _p(i32(mate_flags)), _p(i32(mate_ref)), _p(i32(mate_start)), _p(i32(tlen)), _p(rl), _p(_a(base_off, np.int64)),
+                _p(_u8(bases)), _p(_u8(quals)), _p(_a(has_quals, np.uint8)), _p(i32(n_cigar)), _p(_a(cigar_off, np.int64)),
+                _p(_a(cigar, np.uint32)), _p(nm) if nm is not None else nul, _p(no) if no is not None else nul,
+                ctypes.c_int64(int(name_base)), _p(tg) if tg is not None else nul, _p(to) if to is not None else nul, _p(out),
+                ctypes.c_int64(cap), _p(rec_off), _p(status)))
+    return out[:min(tot, cap)].tobytes(), rec_off, status[:n], tot
+
+
+def bam_index(stripe):
+    """Record offsets of a stripe (Bam_OBA_Supplier.java:49-62) -> int64[n + 1]; raises on a malformed stripe."""
+    s = _u8(stripe)
+    f = lib().orc_bam_index
+    f.restype = ctypes.c_int64
+    n = int(f(_p(s), ctypes.c_int64(len(s)), ctypes.c_void_p(None), ctypes.c_int64(0)))
+    if n < 0:
+        raise RuntimeError("oracle bam_index error %d" % n)
+    off = np.zeros(n + 1, np.int64)
+    f(_p(s), ctypes.c_int64(len(s)), _p(off), ctypes.c_int64(n + 1))
+    return off
+
+
+def bam_decode(stripe, rec_off, bases_cap=None, cigar_cap=None):
+    """BAM records -> dict of columns (see oracle/bam.c orc_bam_decode)."""
+    s = _u8(stripe)
+    ro = _a(rec_off, np.int64)
+    n = len(ro) - 1
+    bases_cap = len(s) * 2 + 16 if bases_cap is None else bases_cap
+    cigar_cap = len(s) // 4 + 1 if cigar_cap is None else cigar_cap
+    z = lambda k, dt: np.zeros(k, dt)
+    o = dict(ref_id=z(n, np.int32), aln_start=z(n, np.int32), mapq=z(n, np.uint8), bam_flags=z(n, np.int32), mate_ref=z(n, np.int32),
+             mate_start=z(n, np.int32), tlen=z(n, np.int32), read_len=z(n, np.int32), base_off=z(n + 1, np.int64),
+             bases=z(max(bases_cap, 1), np.uint8), quals=z(max(bases_cap, 1), np.uint8), n_cigar=z(n, np.int32),
+             cigar_off=z(n + 1, np.int64), cigar=z(max(cigar_cap, 1), np.uint32), aln_span=z(n, np.int32), rflags=z(n, np.uint8),
+             name_off=z(n, np.int64), name_len=z(n, np.int32), tag_off=z(n, np.int64), tag_len=z(n, np.int32),
+             status=z(max(n, 1), np.int32))
+    f = lib().orc_bam_decode
+    f.restype = ctypes.c_int64
+    r = int(f(ctypes.c_int32(n), _p(s), _p(ro), _p(o["ref_id"]), _p(o["aln_start"]), _p(o["mapq"]), _p(o["bam_flags"]),
+              _p(o["mate_ref"]), _p(o["mate_start"]), _p(o["tlen"]), _p(o["read_len"]), _p(o["base_off"]), _p(o["bases"]),
+              _p(o["quals"]), ctypes.c_int64(bases_cap), _p(o["n_cigar"]), _p(o["cigar_off"]), _p(o["cigar"]),
+              ctypes.c_int64(cigar_cap), _p(o["aln_span"]), _p(o["rflags"]), _p(o["name_off"]), _p(o["name_len"]), _p(o["tag_off"]),
+              _p(o["tag_len"]), _p(o["status"])))
+    o["status"] = o["status"][:n]
+    o["ret"] = r
+    return o

@@ -263,7 +263,7 @@ int64_t orc_read_series(int32_t n_reads, const uint8_t* in, int64_t cap, const i
         seq_off[r] = nseq;
         feat_off[r] = nf;
         memset(quals_out + nb, 0xFF, (size_t)L);
-        mapq[r] = 255;
+        mapq[r] = 0; /* SAMRecord.NO_MAPPING_QUALITY (ReaderToBAM.java:157); a record without MQ keeps the field's 0 */
         if (!(bam_flags[r] & BAM_UNMAPPED)) {
             int32_t n;
             TRY(get_i(&s[FN], &n));

@@ -1,0 +1,91 @@
+"""Random batches of records for the container-assembly / BAM tests (tests/test_oracle_bam.py, tests/test_bam_gpu.py)
+and a plain-Python statement of one BAM alignment record as the SAM specification §4.2 lays it out."""
+import struct
+
+import numpy as np
+
+from tests import series_cases as sc
+
+NYBBLE = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+NYBBLE.update({c.lower(): i for c, i in list(NYBBLE.items()) if c.isalpha()})
+NYBBLE["."] = 15
+
+
+def reg2bin(beg, end):
+    """SAM specification §5.3 (0-based, half-open)."""
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def py_bam_record(ref_id, pos1, mapq, bin_, flag, name, cigar_words, seq, qual, mate_ref, mate_pos1, tlen, tags=b""):
+    """block_size + the record of SAM specification §4.2: every field little-endian, seq 4 bits per base (high nybble
+    first), qual raw bytes (0xFF x l_seq when absent)."""
+    L = len(seq)
+    packed = bytearray((L + 1) // 2)
+    for i, c in enumerate(seq):
+        packed[i >> 1] |= NYBBLE[c] << (0 if i & 1 else 4)
+    body = struct.pack("<iiBBHHHiiii", ref_id, pos1 - 1, len(name) + 1, mapq, bin_, len(cigar_words), flag, L, mate_ref,
+                       mate_pos1 - 1, tlen)
+    body += name.encode() + b"\0" + b"".join(struct.pack("<I", w) for w in cigar_words) + bytes(packed)
+    body += bytes(qual) if qual is not None else b"\xff" * L
+    body += tags
+    return struct.pack("<i", len(body)) + body
+
+
+def random_batch(rng, sizes, max_len=60):
+    """Containers of random records (series_cases.random_slice) with next-fragment distances that stay inside their
+    container (a few records point at the same mate, a few point outside), lengths that fit 32-bit positions, a sequence
+    id per container and read names / tags for every record."""
+    parts = [sc.random_slice(rng, n, max_len=max_len) for n in sizes]
+    n = sum(sizes)
+    cat = lambda f: np.concatenate([f(p) for p in parts])
+    cols = {k: cat(lambda p: p["cols"][k]).astype(np.int32) for k in sc_cols()}
+    read_len = cat(lambda p: p["read_len"])
+    base_off = np.concatenate([[0], np.cumsum(read_len)]).astype(np.int64)
+    bases = np.concatenate([p["bases"][:int(p["base_off"][-1])] for p in parts] + [np.zeros(16, np.uint8)])
+    quals = np.concatenate([p["quals"][:int(p["base_off"][-1])] for p in parts] + [np.zeros(16, np.uint8)])
+    f_off = np.concatenate([[0], np.cumsum(cat(lambda p: np.diff(p["feats"]["off"])))]).astype(np.int64)
+    feats = dict(off=f_off, **{k: cat(lambda p: p["feats"][k]) for k in ("op", "pos", "a", "b")})
+    big = np.isin(feats["op"], np.frombuffer(b"HPDN", np.uint8))
+    feats["a"] = np.where(big, feats["a"] % (1 << 18), feats["a"]).astype(np.int32)
+    cont_first = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    cont = np.repeat(np.arange(len(sizes)), sizes)
+    # distances: inside the container for most records that claim a mate downstream
+    for r in range(n):
+        last = int(cont_first[cont[r] + 1]) - 1
+        room = last - r - 1  # largest valid distance
+        roll = rng.random()
+        if room < 0 or roll < 0.03:
+            cols["next_frag"][r] = int(rng.integers(room + 1, room + 50))  # outside: the reference throws
+        elif roll < 0.06:
+            cols["next_frag"][r] = room  # many records point at the last one: shared mates
+        else:
+            cols["next_frag"][r] = int(rng.integers(0, min(room, 6) + 1))
+    cols["bam_flags"] = (cols["bam_flags"] | np.where(rng.random(n) < 0.7, 1, 0)).astype(np.int32)  # mostly paired
+    multiref = (rng.random(len(sizes)) < 0.4).astype(np.uint8)
+    cont_ref_id = rng.integers(-1, 25, len(sizes)).astype(np.int32)
+    ref_id = np.where(multiref[cont] != 0, cols["ref_id"], cont_ref_id[cont]).astype(np.int32)
+    names = [("q%d_%d" % (r, int(rng.integers(0, 10 ** int(rng.integers(1, 9)))))).encode() for r in range(n)]
+    tags = [bytes(rng.integers(0, 256, int(rng.integers(0, 40))).astype(np.uint8)) for r in range(n)]
+    name_off = np.concatenate([[0], np.cumsum([len(x) for x in names])]).astype(np.int64)
+    tag_off = np.concatenate([[0], np.cumsum([len(x) for x in tags])]).astype(np.int64)
+    return dict(n=n, sizes=list(sizes), cont_first=cont_first, cont=cont, cols=cols, read_len=read_len.astype(np.int32),
+                aln_start=cat(lambda p: p["aln_start"]).astype(np.int32), mapq=cat(lambda p: p["mapq"]).astype(np.uint8),
+                base_off=base_off, bases=bases, quals=quals, feats=feats, multiref=multiref, cont_ref_id=cont_ref_id, ref_id=ref_id,
+                names=np.frombuffer(b"".join(names) + b"\0", np.uint8), name_off=name_off,
+                tags=np.frombuffer(b"".join(tags) + b"\0", np.uint8), tag_off=tag_off)
+
+
+def sc_cols():
+    return ("bam_flags", "comp_flags", "ref_id", "read_group", "mate_flags", "mate_ref", "mate_start", "tlen", "next_frag",
+            "tag_list")

@@ -1,0 +1,129 @@
+"""Container assembly and BAM records on the device (cramgpu_cigars_dev, cramgpu_restore_mates_dev,
+cramgpu_bam_encode_dev, cramgpu_bam_decode_dev) against the oracle (oracle/bam.c): random
+containers with every operator and record kind, shared and out-of-range mate links, names / tags present and generated,
+records without scores, bases outside the 4-bit table, the capacity guards, and encode -> decode round trips."""
+import numpy as np
+import pytest
+
+from tests import bam_cases as bc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _t(x, dt=None):
+    import torch
+    t = torch.as_tensor(np.ascontiguousarray(x))
+    return (t.to(dt) if dt is not None else t).to(DEV)
+
+
+def _setup(b):
+    from cramtools_amd import records
+    import torch
+    f = b["feats"]
+    feats = records.FeatureBatch.from_host(DEV, f["op"], f["pos"], f["a"], f["b"], f["off"])
+    cols = records.RecordColumns(DEV, b["n"], multiref=b["multiref"], **b["cols"])
+    return feats, cols, _t(b["read_len"]), _t(b["aln_start"]), torch
+
+
+@pytest.mark.parametrize("seed,sizes", [(0, [1]), (1, [300]), (2, [700, 5, 256, 257]), (3, [64, 1, 1000])])
+def test_assembly_and_encode_match_oracle(orc, seed, sizes):
+    from cramtools_amd import bam, external_compression as xc
+    rng = np.random.default_rng(200 + seed)
+    b = bc.random_batch(rng, sizes)
+    c = b["cols"]
+    eng = xc.Engine(0)
+    try:
+        feats, cols, read_len, aln_start, torch = _setup(b)
+        fac = bam.Cram2SamRecordFactory(eng, DEV)
+        # --- CIGARs and alignment ends
+        want = orc.cigars(b["read_len"], b["aln_start"], c["bam_flags"], b["feats"])
+        n_cigar, cigar_off, cigar, aln_end = fac.cigars(read_len, aln_start, cols.bam_flags, feats)
+        assert np.array_equal(n_cigar.cpu().numpy(), want["n_cigar"])
+        assert np.array_equal(cigar_off.cpu().numpy(), want["cigar_off"])
+        assert np.array_equal(cigar.cpu().numpy().view(np.uint32)[:want["total"]], want["cigar"][:want["total"]])
+        assert np.array_equal(aln_end.cpu().numpy(), want["aln_end"])
+        if want["total"] > 1:
+            with pytest.raises(bam._lib.CramGpuError) as ei:
+                fac.cigars(read_len, aln_start, cols.bam_flags, feats, cigar_cap=want["total"] - 1)
+            assert ei.value.code == -3
+        # --- mates
+        w_cols, w_st = orc.restore_mates(b["cont_first"], c, b["ref_id"], b["aln_start"], want["aln_end"])
+        st = fac.restore_mates(cols, _t(b["cont_first"]), _t(b["cont_ref_id"]), aln_start, aln_end)
+        assert np.array_equal(st.cpu().numpy(), w_st)
+        assert np.array_equal(cols.ref_id.cpu().numpy(), b["ref_id"])
+        good = (w_st == 0)[b["cont"]]  # a container the reference throws on: next_frag is unspecified, the mate columns stay
+        for k in ("next_frag", "mate_flags", "mate_ref", "mate_start", "tlen"):
+            sel = good if k == "next_frag" else slice(None)
+            assert np.array_equal(getattr(cols, k).cpu().numpy()[sel], w_cols[k][sel]), k
+        # --- BAM records: names and tags from the host, a fifth of the records without scores
+        codec = bam.BAMRecordCodec(eng, DEV)
+        qual_status = (rng.random(b["n"]) < 0.2).astype(np.int32)
+        if seed == 2:
+            b["bases"] = b["bases"].copy()
+            b["bases"][rng.integers(0, int(b["base_off"][-1]), 30)] = rng.choice(np.frombuffer(b"=acgtnMRSVWYHKDB.@x", np.uint8), 30)
+        args = (b["ref_id"], b["aln_start"], want["aln_end"], b["mapq"], c["bam_flags"], w_cols["mate_flags"], w_cols["mate_ref"],
+                w_cols["mate_start"], w_cols["tlen"], b["read_len"], b["base_off"], b["bases"], b["quals"], 1 - qual_status,
+                want["n_cigar"], want["cigar_off"], want["cigar"])
+        w_bam, w_off, w_status, tot = orc.bam_encode(*args, names=b["names"], name_off=b["name_off"], tags=b["tags"], tag_off=b["tag_off"])
+        bases, quals, base_off, mapq = _t(b["bases"]), _t(b["quals"]), _t(b["base_off"]), _t(b["mapq"])
+        enc = lambda cap, **kw: codec.encode(cols, read_len, aln_start, aln_end, mapq, base_off, bases, quals, n_cigar, cigar_off,
+                                             cigar, cap, qual_status=_t(qual_status), **kw)
+        kw = dict(names=_t(b["names"]), name_off=_t(b["name_off"]), tags=_t(b["tags"]), tag_off=_t(b["tag_off"]))
+        g_bam, g_off, g_status = enc(tot, **kw)
+        assert np.array_equal(g_off.cpu().numpy(), w_off)
+        assert np.array_equal(g_status.cpu().numpy(), w_status)
+        assert (w_status != 0).any() == (seed == 2)
+        assert g_bam[:tot].cpu().numpy().tobytes() == w_bam
+        # capacity guard: nothing written, every record says so, the need is reported
+        g_bam, g_off, g_status = enc(tot - 1, **kw)
+        assert int(g_off[-1].item()) == tot and (g_status.cpu().numpy() == -3).all() and not g_bam.any().item()
+        # generated names, no tags
+        w_bam2, w_off2, _, tot2 = orc.bam_encode(*args, name_base=10 ** 9 - 5)
+        g_bam, g_off, _ = enc(tot2, name_base=10 ** 9 - 5)
+        assert np.array_equal(g_off.cpu().numpy(), w_off2) and g_bam[:tot2].cpu().numpy().tobytes() == w_bam2
+        # --- and back: the stripe decodes to what the oracle's decoder says
+        stripe = np.frombuffer(w_bam, np.uint8)
+        rec_off = codec.index(stripe)
+        assert np.array_equal(rec_off, w_off)
+        wd = orc.bam_decode(stripe, rec_off)
+        nb, ncg = int(wd["base_off"][-1]), int(wd["cigar_off"][-1])
+        d = codec.decode(_t(np.concatenate([stripe, np.zeros(16, np.uint8)])), _t(rec_off), nb, ncg)
+        for k in ("ref_id", "aln_start", "mapq", "bam_flags", "mate_ref", "mate_start", "tlen", "read_len", "base_off", "n_cigar",
+                  "cigar_off", "aln_span", "rflags", "name_off", "name_len", "tag_off", "tag_len", "status"):
+            assert np.array_equal(d[k].cpu().numpy(), wd[k]), k
+        assert np.array_equal(d["bases"][:nb].cpu().numpy(), wd["bases"][:nb])
+        assert np.array_equal(d["quals"][:nb].cpu().numpy(), wd["quals"][:nb])
+        assert np.array_equal(d["cigar"].cpu().numpy().view(np.uint32)[:ncg], wd["cigar"][:ncg])
+        if nb > 0:
+            d = codec.decode(_t(np.concatenate([stripe, np.zeros(16, np.uint8)])), _t(rec_off), nb - 1, ncg)
+            assert (d["status"].cpu().numpy() == -3).all() and int(d["base_off"][-1].item()) == nb
+    finally:
+        eng.close()
+
+
+def test_decoder_flags_malformed_records(orc):
+    from cramtools_amd import bam, external_compression as xc
+    rng = np.random.default_rng(5)
+    recs = [bc.py_bam_record(1, 100 + i, 20, 0, 0, "n%d" % i, [(10 + i) << 4], "ACGTACGTAC" + "G" * i, bytes(range(10 + i)), -1, 0, 0)
+            for i in range(6)]
+    bad = bytearray(recs[2])
+    bad[20:24] = (10 ** 6).to_bytes(4, "little")  # l_seq runs past the record
+    recs[2] = bytes(bad)
+    stripe = np.frombuffer(b"".join(recs), np.uint8)
+    rec_off = orc.bam_index(stripe)
+    wd = orc.bam_decode(stripe, rec_off)
+    assert wd["status"].tolist() == [0, 0, -5, 0, 0, 0]
+    eng = xc.Engine(0)
+    try:
+        codec = bam.BAMRecordCodec(eng, DEV)
+        d = codec.decode(_t(np.concatenate([stripe, np.zeros(16, np.uint8)])), _t(rec_off), int(wd["base_off"][-1]), 6)
+        for k in ("status", "read_len", "base_off", "rflags", "aln_start", "n_cigar"):
+            assert np.array_equal(d[k].cpu().numpy(), wd[k]), k
+        nb = int(wd["base_off"][-1])
+        assert np.array_equal(d["bases"][:nb].cpu().numpy(), wd["bases"][:nb])
+        with pytest.raises(bam._lib.CramGpuError):
+            codec.index(stripe[:-3])
+    finally:
+        eng.close()

@@ -160,3 +160,13 @@ def test_series_writer_test_bodies(hostsim, orc, monkeypatch):
     t.test_writer_feeds_the_encoder(orc)
     t.test_reader_matches_oracle_and_inverts_writer(orc, 0, [1])
     t.test_reader_matches_oracle_and_inverts_writer(orc, 2, [300, 5, 257])
+
+
+def test_bam_test_bodies(hostsim, orc, monkeypatch):
+    """tests/test_bam_gpu.py on the host build of csrc/bam.hip."""
+    import test_bam_gpu as t
+    monkeypatch.setattr(t, "DEV", "cpu")
+    t.test_assembly_and_encode_match_oracle(orc, 0, [1])
+    t.test_assembly_and_encode_match_oracle(orc, 2, [300, 5, 257])
+    t.test_decoder_flags_malformed_records(orc)
+

@@ -1,0 +1,172 @@
+"""The container-assembly / BAM oracle (oracle/bam.c) against answers worked by hand from the reference's sources:
+CIGARs from features (ReadFeatureBuffer.java:180-294), mate restoration (CramNormalizer.java:82-105, :255-285, :455-470),
+one BAM record against an independent plain-Python statement of the SAM specification's layout (the layout
+BAMRecordView.java:23-35 writes), and encode -> index -> decode round trips.  No fixture of the reference holds these
+outputs ("parity unpinned" at the reference level)."""
+import numpy as np
+import pytest
+
+from tests import bam_cases as bc
+
+M, I, D, N, S, H, P = range(7)
+
+
+def _feats(per_read):
+    """per_read: list of lists of (op char, pos, a, b)."""
+    off = np.concatenate([[0], np.cumsum([len(f) for f in per_read])]).astype(np.int64)
+    flat = [x for f in per_read for x in f]
+    return dict(off=off, op=np.array([ord(x[0]) for x in flat], np.uint8), pos=np.array([x[1] for x in flat], np.int32),
+                a=np.array([x[2] for x in flat], np.int32), b=np.array([x[3] for x in flat], np.int32))
+
+
+CIGAR_CASES = [
+    # (read length, features, expected elements, expected span)
+    (100, [], [(100, M)], 100),
+    (100, [("X", 50, 0, 0)], [(100, M)], 100),
+    (100, [("S", 1, 0, 5)], [(5, S), (95, M)], 95),
+    (100, [("D", 51, 3, 0)], [(50, M), (3, D), (50, M)], 103),
+    (30, [("I", 11, 10, 2), ("X", 20, 0, 0)], [(10, M), (2, I), (18, M)], 28),
+    (10, [("H", 1, 5, 0), ("S", 1, 0, 3)], [(5, H), (3, S), (7, M)], 7),
+    (10, [("Q", 5, 30, 0)], [(10, M)], 10),
+    (10, [("S", 7, 6, 4)], [(6, M), (4, S)], 6),
+    (10, [("i", 3, 65, 0), ("i", 4, 67, 0)], [(2, M), (2, I), (6, M)], 8),
+    (20, [("N", 6, 1000, 0), ("B", 9, 65, 30)], [(5, M), (1000, N), (15, M)], 20),
+    (8, [("P", 4, 2, 0), ("D", 4, 1, 0)], [(3, M), (2, P), (1, D), (5, M)], 9),
+    (5, [("X", 1, 0, 0), ("X", 5, 0, 0)], [(5, M)], 5),
+]
+
+
+def test_cigar_known_answers(orc):
+    read_len = np.array([c[0] for c in CIGAR_CASES] + [40], np.int32)
+    start = np.arange(100, 100 + len(read_len)).astype(np.int32)
+    flags = np.zeros(len(read_len), np.int32)
+    flags[-1] = 4  # unmapped: no CIGAR, end 0
+    got = orc.cigars(read_len, start, flags, _feats([c[1] for c in CIGAR_CASES] + [[]]))
+    for r, (L, _, want, span) in enumerate(CIGAR_CASES):
+        o0, k = int(got["cigar_off"][r]), int(got["n_cigar"][r])
+        assert [(int(w) >> 4, int(w) & 15) for w in got["cigar"][o0:o0 + k]] == want, r
+        assert got["aln_end"][r] == start[r] + span - 1, r
+    assert got["n_cigar"][-1] == 0 and got["aln_end"][-1] == 0
+    assert got["total"] == sum(len(c[2]) for c in CIGAR_CASES) == got["cigar_off"][-1]
+    small = orc.cigars(read_len, start, flags, _feats([c[1] for c in CIGAR_CASES] + [[]]), cigar_cap=3)
+    assert small["total"] == got["total"] and not small["cigar"].any()
+
+
+def _cols(n, **kw):
+    c = {k: np.zeros(n, np.int32) for k in bc.sc_cols()}
+    for k, v in kw.items():
+        c[k] = np.asarray(v, np.int32)
+    return c
+
+
+def test_mate_restoration_known_answers(orc):
+    # records: 0 -> 1 (pair, second on the reverse strand), 2 detached, 3 -> 4 -> 5 (three fragments, 5 unmapped), 6 unpaired
+    bf = [1 | 64, 1 | 16 | 128, 1, 1, 1 | 16, 1 | 4, 0]
+    cf = [4, 0, 2, 4, 4, 0, 4]
+    nf = [0, 0, 7, 0, 0, 0, 0]
+    cols = _cols(7, bam_flags=bf, comp_flags=cf, next_frag=nf, mate_start=[9] * 7, mate_ref=[8] * 7, tlen=[7] * 7, mate_flags=[3] * 7)
+    start = np.array([100, 300, 500, 1000, 1100, 1100, 50], np.int32)
+    end = np.array([199, 399, 599, 1099, 1199, 0, 149], np.int32)
+    ref = np.array([2, 2, 2, 2, 2, -1, 2], np.int32)
+    out, st = orc.restore_mates([0, 7], cols, ref, start, end)
+    assert st[0] == 0
+    assert out["mate_start"].tolist() == [300, 100, 9, 1100, 0, 1000, 9]       # :279, :283-284 (mate without reference: start 0)
+    assert out["mate_ref"].tolist() == [2, 2, 8, 2, -1, 2, 8]
+    assert out["mate_flags"].tolist() == [1, 0, 3, 1, 2, 0, 3]                  # :280-281
+    assert out["tlen"].tolist() == [300, -300, 7, 0, 7, 0, 7]                   # :455-470: 399 - 100 + 1; an unmapped end: 0
+    assert out["next_frag"].tolist() == [0, 0, -1, 0, 0, 0, -1]                 # :85
+    # a distance that leaves the container: records.get throws
+    cols["next_frag"][4] = 2
+    _, st = orc.restore_mates([0, 7], cols, ref, start, end)
+    assert st[0] == -9
+    # second end in front of the first: negative length (:468)
+    cols = _cols(2, bam_flags=[1, 1], comp_flags=[4, 0])
+    out, st = orc.restore_mates([0, 2], cols, [0, 0], [500, 100], [599, 199])
+    assert out["tlen"].tolist() == [-401, 401]
+
+
+def test_bam_record_known_answer(orc):
+    """The alignment r001/1 of the SAM specification's example (§1.1), field by field."""
+    seq, name = "TTAGATAAAGGATACTG", "r001"
+    cig = [(8, M), (2, I), (4, M), (1, D), (3, M)]
+    words = [(l << 4) | o for l, o in cig]
+    qual = bytes(range(20, 20 + len(seq)))
+    end = 7 + 8 + 4 + 1 + 3 - 1
+    tags = b"NMC\x01"
+    want = bc.py_bam_record(0, 7, 30, bc.reg2bin(6, end), 99, name, words, seq, qual, 0, 37, 39, tags)
+    bases = np.frombuffer(seq.encode(), np.uint8)
+    got, rec_off, status, tot = orc.bam_encode([0], [7], [end], [30], [99 & ~0x20], [1], [0], [37], [39], [len(seq)], [0, len(seq)],
+                                               bases, np.frombuffer(qual, np.uint8), [1], [len(words)], [0, len(words)], words,
+                                               names=np.frombuffer(name.encode(), np.uint8), name_off=[0, 4],
+                                               tags=np.frombuffer(tags, np.uint8), tag_off=[0, 4])
+    assert got == want and tot == len(want) and status[0] == 0 and rec_off.tolist() == [0, len(want)]
+    assert want[:4] == (len(want) - 4).to_bytes(4, "little") and want[36:41] == b"r001\0"
+    assert want[41 + 20:41 + 20 + 9] == bytes([0x88, 0x14, 0x18, 0x11, 0x14, 0x41, 0x81, 0x28, 0x40])  # T=8 A=1 G=4 C=2
+    # no scores -> 0xFF x length (BAMRecordView.java:176-180); generated name = decimal of name_base + r (CramNormalizer.java:108-117)
+    got, _, _, _ = orc.bam_encode([0], [7], [end], [30], [99 & ~0x20], [1], [0], [37], [39], [len(seq)], [0, len(seq)], bases,
+                                  np.frombuffer(qual, np.uint8), [0], [len(words)], [0, len(words)], words, name_base=41)
+    assert got == bc.py_bam_record(0, 7, 30, bc.reg2bin(6, end), 99, "41", words, seq, None, 0, 37, 39)
+    # unplaced, unpaired, unmapped record: start 0 -> pos -1, mapping quality 0, bin 0, no mate (Cram2SamRecordFactory#create)
+    got, _, st, _ = orc.bam_encode([-1], [123], [0], [77], [4], [3], [5], [99], [0], [3], [0, 3], np.frombuffer(b"AC@", np.uint8),
+                                   np.frombuffer(b"\1\2\3", np.uint8), [1], [0], [0, 0], np.zeros(1, np.uint32), name_base=0)
+    want = bc.py_bam_record(-1, 0, 0, 0, 4, "0", [], "ACN", b"\1\2\3", -1, 0, 0)
+    assert got == want and st[0] == -9  # '@' is outside the 4-bit table: BAMRecordView.java:412 throws
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_encode_index_decode_round_trip(orc, seed):
+    rng = np.random.default_rng(40 + seed)
+    b = bc.random_batch(rng, [50, 1, 120] if seed else [1])
+    c = b["cols"]
+    cg = orc.cigars(b["read_len"], b["aln_start"], c["bam_flags"], b["feats"])
+    has_q = (rng.random(b["n"]) < 0.8).astype(np.uint8)
+    stripe, rec_off, status, tot = orc.bam_encode(b["ref_id"], b["aln_start"], cg["aln_end"], b["mapq"], c["bam_flags"], c["mate_flags"],
+                                                  c["mate_ref"], c["mate_start"], c["tlen"], b["read_len"], b["base_off"], b["bases"],
+                                                  b["quals"], has_q, cg["n_cigar"], cg["cigar_off"], cg["cigar"], names=b["names"],
+                                                  name_off=b["name_off"], tags=b["tags"], tag_off=b["tag_off"])
+    assert tot == len(stripe) and not status.any()
+    assert np.array_equal(orc.bam_index(stripe), rec_off)
+    d = orc.bam_decode(stripe, rec_off)
+    assert d["ret"] == int(b["base_off"][-1]) and not d["status"].any()
+    placed = b["ref_id"] != -1
+    paired = (c["bam_flags"] & 1) != 0
+    assert np.array_equal(d["ref_id"], b["ref_id"])
+    assert np.array_equal(d["aln_start"], np.where(placed, b["aln_start"], 0))
+    assert np.array_equal(d["mapq"], np.where(placed, b["mapq"], 0))
+    want_flags = (c["bam_flags"] & ~0x28) | np.where(paired & ((c["mate_flags"] & 1) != 0), 0x20, 0) | \
+        np.where(paired & ((c["mate_flags"] & 2) != 0), 0x8, 0)
+    assert np.array_equal(d["bam_flags"], want_flags & 0xFFFF)
+    assert np.array_equal(d["mate_ref"], np.where(paired, c["mate_ref"], -1))
+    assert np.array_equal(d["mate_start"], np.where(paired & (c["mate_start"] > 0), c["mate_start"], 0))
+    assert np.array_equal(d["tlen"], c["tlen"]) and np.array_equal(d["read_len"], b["read_len"])
+    assert np.array_equal(d["base_off"], b["base_off"]) and np.array_equal(d["n_cigar"], cg["n_cigar"])
+    assert np.array_equal(d["cigar"][:cg["total"]], cg["cigar"][:cg["total"]])
+    nb = int(b["base_off"][-1])
+    assert np.array_equal(d["bases"][:nb], b["bases"][:nb])
+    for r in range(b["n"]):
+        o0, L = int(b["base_off"][r]), int(b["read_len"][r])
+        q = d["quals"][o0:o0 + L]
+        assert np.array_equal(q, b["quals"][o0:o0 + L]) if has_q[r] else (q == 0xFF).all()
+        assert stripe[int(d["name_off"][r]):int(d["name_off"][r]) + int(d["name_len"][r])] == \
+            b["names"][int(b["name_off"][r]):int(b["name_off"][r + 1])].tobytes()
+        assert stripe[int(d["tag_off"][r]):int(d["tag_off"][r]) + int(d["tag_len"][r])] == \
+            b["tags"][int(b["tag_off"][r]):int(b["tag_off"][r + 1])].tobytes()
+        want_rf = (1 if c["bam_flags"][r] & 4 else 0) | (2 if (not has_q[r] or b["quals"][o0] == 0xFF) else 0)
+        assert d["rflags"][r] == want_rf, r
+    # a truncated stripe and a block size below 32 are refused (Bam_OBA_Supplier.java:59-62)
+    with pytest.raises(RuntimeError):
+        orc.bam_index(stripe[:-1])
+    with pytest.raises(RuntimeError):
+        orc.bam_index((8).to_bytes(4, "little") + bytes(8))
+
+
+def test_mates_random_chains_are_consistent(orc):
+    """Properties of CramNormalizer.java:255-285 on random containers: a two-record chain mirrors its ends."""
+    rng = np.random.default_rng(9)
+    b = bc.random_batch(rng, [200, 300])
+    c = b["cols"]
+    cg = orc.cigars(b["read_len"], b["aln_start"], c["bam_flags"], b["feats"])
+    out, st = orc.restore_mates(b["cont_first"], c, b["ref_id"], b["aln_start"], cg["aln_end"])
+    assert set(st.tolist()) <= {0, -9}
+    linked = ((c["bam_flags"] & 1) != 0) & ((c["comp_flags"] & 2) == 0)
+    assert (out["next_frag"][~linked] == -1).all()
