@@ -256,7 +256,10 @@ class DecodeStep:
           bytes and quality arrays,
       N1  CramNormalizer.restoreReadBases for every read from the READER's columns and features (whole-reference window
           per container, matrices on the host as the compression header holds them),
-      N2  CramNormalizer.restoreQualityScores on the reader's quality arrays."""
+      N2  CramNormalizer.restoreQualityScores on the reader's quality arrays,
+      A   container assembly: CIGARs from the features (Cram2SamRecordFactory#getCigar2), mate
+          restoration (CramNormalizer.java:82-105), one BAM record per read (BAMRecordCodec#encode) — the uncompressed
+          stripe CramToBam_OBA_Function hands to BGZF."""
 
     def __init__(self, dev, eng, w, enc):
         self.dev, self.eng, self.w, self.enc = dev, eng, w, enc
@@ -277,11 +280,19 @@ class DecodeStep:
         if enc.writer is not None:
             self.reader = rec.CramRecordReader(eng, dev, reads.n, w["n_cont"], int(reads.bases.numel()), w["feat_cap"],
                                                16 * w["feat_cap"])
+            n_r = reads.n
+            z = lambda k, dt: torch.zeros(k, dtype=dt, device=dev)
+            self.cig_cap = n_r + 2 * w["feat_cap"] + 1
+            self.n_cigar, self.cigar_off, self.cigar = z(n_r, torch.int32), z(n_r + 1, torch.int64), z(self.cig_cap, torch.int32)
+            self.aln_end, self.st_c, self.st_m = z(n_r, torch.int32), z(1, torch.int32), z(w["n_cont"], torch.int32)
+            self.cont_ref_id = z(w["n_cont"], torch.int32)
+            self.bam_cap = n_r * (36 + 12) + 4 * self.cig_cap + 2 * int(reads.bases.numel()) + 64
+            self.bam, self.rec_off, self.st_bam = z(self.bam_cap + 16, torch.uint8), z(n_r + 1, torch.int64), z(n_r, torch.int32)
         else:  # the round-1 form: columns and features of the encode side
             self.bases = torch.zeros(reads.bases.numel() + 16, dtype=torch.uint8, device=dev)
             self.rflags = reads.rflags | 16  # CRAMGPU_RF_FORCE_QS: lossless records carry CF_FORCE_PRESERVE_QS
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        self.k2_ms, self.ms = [], []
+        self.k2_ms, self.ms, self.bam_ms = [], [], []
 
     def run(self, timed=True):
         w, L, reads = self.w, _lib.lib(), self.w["reads"]
@@ -321,6 +332,36 @@ class DecodeStep:
             torch.cuda.synchronize()
             self.k2_ms.append(self.ev[0].elapsed_time(self.ev[1]))
             self.ms.append(self.ev[0].elapsed_time(self.ev[2]))
+
+    def assemble(self, timed=True):
+        """A: what stands between the normalizer and BGZF in CramToBam_OBA_Function.java:64-75, on the reader's columns."""
+        w, L, reads, rd = self.w, _lib.lib(), self.w["reads"], self.reader
+        s = torch.cuda.current_stream().cuda_stream
+        fs = rd.feats.struct()
+        if timed:
+            self.ev[3].record()
+        cs = rd.cols.struct()
+        _lib.check(L.cramgpu_cigars_dev(self.eng.handle, reads.n, rd.read_len.data_ptr(), rd.aln_start.data_ptr(),
+                                        rd.cols.bam_flags.data_ptr(), C.byref(fs), self.n_cigar.data_ptr(),
+                                        self.cigar_off.data_ptr(), self.cigar.data_ptr(), self.cig_cap, self.aln_end.data_ptr(),
+                                        self.st_c.data_ptr(), s))
+        _lib.check(L.cramgpu_restore_mates_dev(self.eng.handle, reads.n, w["n_cont"], self.cont_first.data_ptr(), C.byref(cs),
+                                               self.cont_ref_id.data_ptr(), rd.aln_start.data_ptr(), self.aln_end.data_ptr(),
+                                               self.st_m.data_ptr(), s))
+        b = _lib.BamCols()
+        b.ref_id, b.aln_start, b.aln_end, b.mapq = (rd.cols.ref_id.data_ptr(), rd.aln_start.data_ptr(), self.aln_end.data_ptr(),
+                                                    rd.mapq.data_ptr())
+        b.bam_flags, b.mate_flags, b.mate_ref = rd.cols.bam_flags.data_ptr(), rd.cols.mate_flags.data_ptr(), rd.cols.mate_ref.data_ptr()
+        b.mate_start, b.tlen, b.read_len = rd.cols.mate_start.data_ptr(), rd.cols.tlen.data_ptr(), rd.read_len.data_ptr()
+        b.base_off, b.bases, b.quals, b.qual_status = (rd.base_off.data_ptr(), rd.bases.data_ptr(), rd.quals.data_ptr(),
+                                                       self.st_q.data_ptr())
+        b.n_cigar, b.cigar_off, b.cigar, b.name_base = self.n_cigar.data_ptr(), self.cigar_off.data_ptr(), self.cigar.data_ptr(), 1
+        _lib.check(L.cramgpu_bam_encode_dev(self.eng.handle, reads.n, C.byref(b), self.bam.data_ptr(), self.bam_cap,
+                                            self.rec_off.data_ptr(), self.st_bam.data_ptr(), s))
+        if timed:
+            self.ev[2].record()
+            torch.cuda.synchronize()
+            self.bam_ms.append(self.ev[3].elapsed_time(self.ev[2]))
 
     def prepare(self):
         """Reader tables: where every series of every container lies (rANS series in the decoded arena, the others raw in
@@ -373,6 +414,28 @@ class DecodeStep:
         assert torch.equal(self.bases[:tot], reads.bases[:tot]), "restored bases differ from the reads"
         return "all %d blocks and %d reads round-trip (decoded arena == raw arena, restored bases == read bases)" % (
             w["n_blocks"], reads.n)
+
+
+    def verify_assembly(self):
+        """The BAM stripe: CIGARs rebuilt from the features are the reads' own, and the stripe decodes back to the reads."""
+        w, reads = self.w, self.w["reads"]
+        tot = int(w["rs"].read_len.sum().item())
+        from cramtools_amd import bam as bam_mod
+        ncg = int(reads.n_cigar.sum().item())
+        assert int(self.st_c.item()) == 0 and int((self.st_m != 0).sum().item()) == 0, "CIGAR / mate status"
+        assert int((self.st_bam != 0).sum().item()) == 0, "a BAM record reported a status"
+        assert torch.equal(self.n_cigar, reads.n_cigar) and torch.equal(self.cigar[:ncg], reads.cigar[:ncg]), \
+            "CIGARs rebuilt from the features differ from the reads' CIGARs"
+        size = int(self.rec_off[reads.n].item())
+        d = bam_mod.BAMRecordCodec(self.eng, self.dev).decode(self.bam, self.rec_off, tot, ncg)
+        torch.cuda.synchronize()
+        assert int((d["status"] != 0).sum().item()) == 0, "the BAM stripe does not parse"
+        assert torch.equal(d["bases"][:tot], reads.bases[:tot]) and torch.equal(d["quals"][:tot], reads.quals[:tot]), "BAM seq / qual"
+        assert torch.equal(d["cigar"][:ncg], reads.cigar[:ncg]) and torch.equal(d["aln_start"], reads.aln_start), "BAM cigar / pos"
+        assert torch.equal(d["bam_flags"] & ~0x28, w["cols"].bam_flags & 0xFFD7), "BAM flags"
+        self.bam_bytes = size
+        return ("; the %d-byte BAM stripe built from them (CIGARs from features, mate restoration, BAM records) decodes back to "
+                "the reads" % size)
 
 
 def host_threads():
@@ -632,6 +695,11 @@ def main(argv=None, backend_factory=GpuBackend):
         dec.k2_ms, dec.ms = [], []
         dt_dec = sharding.timed_region(dec.run, a.steps, dist=dist, sync=be.sync)
         dec_parity = dec.verify()
+        if getattr(dec, "reader", None) is not None:  # container assembly + BAM records on the restored reads
+            dec.assemble(False)
+            for _ in range(a.steps):
+                dec.assemble(True)
+            dec_parity += dec.verify_assembly()
 
     # parity verdict on this rank's blocks: no negative lengths, and the sampled containers equal the CPU oracle
     lens = step.d_len.cpu().numpy()
@@ -665,6 +733,13 @@ def main(argv=None, backend_factory=GpuBackend):
                                    ms_per_step=dec_s * 1e3, rans_decode_kernel_ms=k2_s * 1e3,
                                    rans_decode_GBps=algo / k2_s / 1e9, rans_decode_frac_of_hbm=algo / k2_s / 1e9 / HBM_PEAK_GBS,
                                    parity=dec_parity)
+            if getattr(dec, "bam_ms", None):
+                bam_s = float(np.mean(dec.bam_ms)) / 1e3
+                extra["decode"]["assembly"] = dict(
+                    workload="SURVEY 8(f) rows 4 + 3 on the decoded reads: CIGARs from features, mate restoration, one BAM record "
+                             "per read (the uncompressed stripe handed to BGZF); outside the decode leg's time",
+                    ms=bam_s * 1e3, bam_bytes=dec.bam_bytes, GBps_written=dec.bam_bytes / bam_s / 1e9,
+                    reads_per_s=a.reads / bam_s)
         if not a.no_pcie and world == 1:
             extra["pcie_inclusive"] = be.pcie(w)
         total_raw = w["raw_bytes"] * world
