@@ -114,3 +114,17 @@ class BAMRecordCodec:
                                                      status.data_ptr(), _stream()))
         o["status"] = status[:n]
         return o
+
+
+def slice_ref_md5(engine, device, d_ref, windows, start, span):
+    """htsjdk!structure/Slice#setRefMD5 for a batch of slices (cramgpu_slice_md5_dev): windows = (ref_off, ref_len,
+    ref_start0) per slice, start / span = the slices' 1-based alignment start and span.  -> uint8[n, 16] device tensor."""
+    torch = _torch()
+    n = len(start)
+    win = _dev(np.asarray(windows, np.int64).reshape(-1), torch.int64, device)
+    st, sp = _dev(start, torch.int32, device), _dev(span, torch.int32, device)
+    out = torch.zeros(max(n, 1) * 16, dtype=torch.uint8, device=device)
+    _lib.check(_lib.lib().cramgpu_slice_md5_dev(engine.handle, n, d_ref.data_ptr(), win.data_ptr(), st.data_ptr(), sp.data_ptr(),
+                                                out.data_ptr(), _stream()))
+    return out[:n * 16].reshape(n, 16)
+

@@ -1044,6 +1044,17 @@ int32_t cramgpu_bam_decode_dev(cramgpu_ctx* c, int32_t n_reads, const uint8_t* d
     return 0;
 }
 
+int32_t cramgpu_slice_md5_dev(cramgpu_ctx* c, int32_t n_slices, const uint8_t* d_ref, const cramgpu_refwin* d_wins,
+                              const int32_t* d_start, const int32_t* d_span, uint8_t* d_md5, void* stream) {
+    if (!c || n_slices < 0 || !d_ref || !d_wins || !d_start || !d_span || !d_md5) return fail(CRAMGPU_E_ARG, "slice_md5: bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(launch_slice_md5(n_slices, d_ref, d_wins, d_start, d_span, d_md5, s));
+    return 0;
+}
+
 int64_t cramgpu_bam_index(const uint8_t* bam, int64_t len, int64_t* rec_off, int64_t cap) {
     if (!bam || len < 0 || (cap > 0 && !rec_off)) return fail(CRAMGPU_E_ARG, "bam_index: bad argument");
     int64_t at = 0, n = 0;

@@ -520,6 +520,98 @@ __global__ __launch_bounds__(256) void bam_body_kernel(int32_t n, const uint8_t*
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Slice reference MD5 — htsjdk!structure/Slice#setRefMD5 (L145-177) on encode (CramSerilization.java:184-197), the check of
+// src/main/java/net/sf/cram/Cram2Bam.java:212-234 through src/main/java/net/sf/cram/ref/ReferenceRegion.java:116-124 on
+// decode: MD5 (RFC 1321) of the reference bases the slice spans, the span clipped at the end of the reference.
+// One chain of 64 dependent rounds per 64-byte block and no parallelism inside a message: a thread per slice, the
+// slices of a batch side by side (a 64 KB span is ~1000 blocks, ~2 M cycles).
+// ---------------------------------------------------------------------------------------------------------------
+__constant__ uint32_t kMd5K[64] = {
+    0xd76aa478u, 0xe8c7b756u, 0x242070dbu, 0xc1bdceeeu, 0xf57c0fafu, 0x4787c62au, 0xa8304613u, 0xfd469501u, 0x698098d8u, 0x8b44f7afu,
+    0xffff5bb1u, 0x895cd7beu, 0x6b901122u, 0xfd987193u, 0xa679438eu, 0x49b40821u, 0xf61e2562u, 0xc040b340u, 0x265e5a51u, 0xe9b6c7aau,
+    0xd62f105du, 0x02441453u, 0xd8a1e681u, 0xe7d3fbc8u, 0x21e1cde6u, 0xc33707d6u, 0xf4d50d87u, 0x455a14edu, 0xa9e3e905u, 0xfcefa3f8u,
+    0x676f02d9u, 0x8d2a4c8au, 0xfffa3942u, 0x8771f681u, 0x6d9d6122u, 0xfde5380cu, 0xa4beea44u, 0x4bdecfa9u, 0xf6bb4b60u, 0xbebfbc70u,
+    0x289b7ec6u, 0xeaa127fau, 0xd4ef3085u, 0x04881d05u, 0xd9d4d039u, 0xe6db99e5u, 0x1fa27cf8u, 0xc4ac5665u, 0xf4292244u, 0x432aff97u,
+    0xab9423a7u, 0xfc93a039u, 0x655b59c3u, 0x8f0ccc92u, 0xffeff47du, 0x85845dd1u, 0x6fa87e4fu, 0xfe2ce6e0u, 0xa3014314u, 0x4e0811a1u,
+    0xf7537e82u, 0xbd3af235u, 0x2ad7d2bbu, 0xeb86d391u};
+
+struct Md5 {
+    uint32_t a, b, c, d;
+};
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+__device__ void md5_block(Md5& h, const uint32_t* m) {
+    constexpr int S[4][4] = {{7, 12, 17, 22}, {5, 9, 14, 20}, {4, 11, 16, 23}, {6, 10, 15, 21}};
+    uint32_t a = h.a, b = h.b, c = h.c, d = h.d;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        uint32_t f;
+        int g;
+        if (i < 16)
+            f = (b & c) | (~b & d), g = i;
+        else if (i < 32)
+            f = (d & b) | (~d & c), g = (5 * i + 1) & 15;
+        else if (i < 48)
+            f = b ^ c ^ d, g = (3 * i + 5) & 15;
+        else
+            f = c ^ (b | ~d), g = (7 * i) & 15;
+        const uint32_t t = d;
+        d = c;
+        c = b;
+        b = b + rotl32(a + f + kMd5K[i] + m[g], S[i >> 4][i & 3]);
+        a = t;
+    }
+    h.a += a, h.b += b, h.c += c, h.d += d;
+}
+
+__global__ __launch_bounds__(64) void slice_md5_kernel(int32_t n, const uint8_t* ref, const cramgpu_refwin* win,
+                                                       const int32_t* start, const int32_t* span, uint8_t* md5) {
+    const int32_t sidx = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (sidx >= n) return;
+    U32x4u* out = reinterpret_cast<U32x4u*>(md5 + 16 * (int64_t)sidx);
+    U32x4u o;
+    if (start[sidx] < 1) {  // a slice without alignment start: 16 zero bytes (Slice#setRefMD5's empty case)
+        o.v[0] = o.v[1] = o.v[2] = o.v[3] = 0u;
+        *out = o;
+        return;
+    }
+    const cramgpu_refwin W = win[sidx];
+    const int64_t from = (int64_t)start[sidx] - 1 - W.ref_start0;  // ReferenceRegion.java:117-123
+    int64_t len = 0;
+    if (from >= 0 && from < W.ref_len) {
+        len = span[sidx] < 0 ? 0 : span[sidx];
+        if (len > W.ref_len - from) len = W.ref_len - from;
+    }
+    const uint8_t* p = ref + W.ref_off + (from > 0 ? from : 0);
+    Md5 h{0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
+    uint32_t m[16];
+    int64_t at = 0;
+    for (; at + 64 <= len; at += 64) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const U32x4u t = *reinterpret_cast<const U32x4u*>(p + at + 16 * q);
+            m[4 * q] = t.v[0], m[4 * q + 1] = t.v[1], m[4 * q + 2] = t.v[2], m[4 * q + 3] = t.v[3];
+        }
+        md5_block(h, m);
+    }
+    // the tail: remaining bytes, 0x80, zeros, the bit length (one or two blocks)
+    const int rem = (int)(len - at);
+#pragma unroll
+    for (int q = 0; q < 16; q++) m[q] = 0u;
+    for (int j = 0; j < rem; j++) m[j >> 2] |= (uint32_t)p[at + j] << (8 * (j & 3));
+    m[rem >> 2] |= 0x80u << (8 * (rem & 3));
+    if (rem >= 56) {
+        md5_block(h, m);
+#pragma unroll
+        for (int q = 0; q < 16; q++) m[q] = 0u;
+    }
+    const unsigned long long bits = (unsigned long long)len * 8ull;
+    m[14] = (uint32_t)bits, m[15] = (uint32_t)(bits >> 32);
+    md5_block(h, m);
+    o.v[0] = h.a, o.v[1] = h.b, o.v[2] = h.c, o.v[3] = h.d;
+    *out = o;
+}
+
 inline dim3 grid1(int64_t n, int per_block) { return dim3((unsigned)((n + per_block - 1) / per_block > 0 ? (n + per_block - 1) / per_block : 1)); }
 
 }  // namespace
@@ -567,5 +659,12 @@ hipError_t launch_bam_decode(int32_t n, const uint8_t* bam, const int64_t* rec_o
     if (e == hipSuccess) e = launch_feature_scan(n, o.n_cigar, o.cigar_off, d_total, d_scan_ws, s);
     if (e != hipSuccess || n == 0) return e;
     hipLaunchKernelGGL(bam_body_kernel, grid1(n, 256 / kSub), dim3(256), 0, s, n, bam, rec_off, o, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_slice_md5(int32_t n, const uint8_t* ref, const cramgpu_refwin* win, const int32_t* start, const int32_t* span,
+                            uint8_t* md5, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(slice_md5_kernel, grid1(n, 64), dim3(64), 0, s, n, ref, win, start, span, md5);
     return hipGetLastError();
 }

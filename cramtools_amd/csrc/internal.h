@@ -102,3 +102,5 @@ hipError_t launch_bam_encode(int32_t n, const cramgpu_bam_cols& b, uint8_t* bam,
                              int32_t* d_sizes, int64_t* d_total, int64_t* d_scan_ws, hipStream_t s);
 hipError_t launch_bam_decode(int32_t n, const uint8_t* bam, const int64_t* rec_off, const cramgpu_bam_out& o, int32_t* status,
                              int64_t* d_total, int64_t* d_scan_ws, hipStream_t s);
+hipError_t launch_slice_md5(int32_t n, const uint8_t* ref, const cramgpu_refwin* win, const int32_t* start, const int32_t* span,
+                            uint8_t* md5, hipStream_t s);

@@ -409,6 +409,15 @@ int32_t cramgpu_restore_mates_dev(cramgpu_ctx* ctx, int32_t n_reads, int32_t n_c
                                   const cramgpu_record_cols* cols, const int32_t* d_cont_ref_id, const int32_t* d_aln_start,
                                   const int32_t* d_aln_end, int32_t* d_status, void* stream);
 
+/* Slice reference MD5 — htsjdk!structure/Slice#setRefMD5 (L145-177), called per slice from
+ * src/main/java/htsjdk/samtools/cram/CramSerilization.java:184-197, and the value src/main/java/net/sf/cram/Cram2Bam.java
+ * :212-234 checks through src/main/java/net/sf/cram/ref/ReferenceRegion.java:116-124: MD5 (RFC 1321) of the reference bases
+ * at the 1-based positions [d_start[s], d_start[s] + d_span[s]), clipped at the end of the slice's window d_wins[s]
+ * (MD5 of nothing when the start lies beyond it).  d_start[s] < 1 (a slice of unplaced records): 16 zero bytes.
+ * d_md5[16 * n_slices].  Stream-ordered, does not synchronise. */
+int32_t cramgpu_slice_md5_dev(cramgpu_ctx* ctx, int32_t n_slices, const uint8_t* d_ref, const cramgpu_refwin* d_wins,
+                              const int32_t* d_start, const int32_t* d_span, uint8_t* d_md5, void* stream);
+
 /* The columns of one batch of records as BAMRecordCodec#encode needs them (device arrays, [n_reads] unless noted). */
 typedef struct {
     const int32_t* ref_id;      /* sequence id of the record (-1 = unplaced) */

@@ -553,3 +553,18 @@ def bam_decode(stripe, rec_off, bases_cap=None, cigar_cap=None):
     o["status"] = o["status"][:n]
     o["ret"] = r
     return o
+
+
+def slice_md5(ref, start, span, ref_start0=0):
+    """The bytes src/main/java/net/sf/cram/ref/ReferenceRegion.java:116-124 hashes for a slice (and htsjdk
+    Slice#setRefMD5 L145-177 on encode): ref = the window's bases, holding 0-based positions from ref_start0.  MD5 itself
+    is Python's hashlib (RFC 1321): an implementation independent of the kernel.  start < 1 -> 16 zero bytes."""
+    import hashlib
+    if start < 1:
+        return bytes(16)
+    ref = bytes(ref)
+    frm = start - 1 - ref_start0
+    if frm < 0 or frm >= len(ref):
+        return hashlib.md5(b"").digest()
+    return hashlib.md5(ref[frm:frm + min(max(span, 0), len(ref) - frm)]).digest()
+

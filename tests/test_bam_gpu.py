@@ -127,3 +127,33 @@ def test_decoder_flags_malformed_records(orc):
             codec.index(stripe[:-3])
     finally:
         eng.close()
+
+
+def test_slice_md5_matches_hashlib(orc):
+    """RFC 1321's own vectors, every tail length around the padding boundaries, unaligned starts, spans clipped at the end of
+    the window, a start beyond it, an unplaced slice."""
+    from cramtools_amd import bam, external_compression as xc
+    import torch
+    rng = np.random.default_rng(3)
+    ref = rng.choice(np.frombuffer(b"ACGTN", np.uint8), 70000)
+    ref[:3] = np.frombuffer(b"abc", np.uint8)
+    msg = b"12345678901234567890123456789012345678901234567890123456789012345678901234567890"
+    ref[100:100 + len(msg)] = np.frombuffer(msg, np.uint8)
+    cases = [(1, 3, 0, 70000, 0), (1, 0, 0, 70000, 0), (101, len(msg), 0, 70000, 0)]
+    cases += [(7, L, 0, 70000, 0) for L in list(range(50, 70)) + [119, 120, 121, 127, 128, 129]]
+    cases += [(int(rng.integers(1, 5000)), int(rng.integers(0, 66000)), 0, 70000, 0) for _ in range(40)]
+    cases += [(69990, 500, 0, 70000, 0), (70001, 10, 0, 70000, 0), (0, 10, 0, 70000, 0), (-5, 0, 0, 70000, 0)]
+    cases += [(1500, 900, 1000, 2000, 1200), (2500, 900, 1000, 2000, 1200), (3201, 5, 1000, 2000, 1200)]  # windows inside the arena
+    want = [orc.slice_md5(ref[off:off + ln], st, sp, s0) for st, sp, off, ln, s0 in cases]
+    assert want[0].hex() == "900150983cd24fb0d6963f7d28e17f72" and want[1].hex() == "d41d8cd98f00b204e9800998ecf8427e"
+    assert want[2].hex() == "57edf4a22be3c955ac49da2e2107b67a"
+    eng = xc.Engine(0)
+    try:
+        d_ref = _t(np.concatenate([ref, np.zeros(16, np.uint8)]))
+        got = bam.slice_ref_md5(eng, DEV, d_ref, [(c[2], c[3], c[4]) for c in cases], [c[0] for c in cases], [c[1] for c in cases])
+        got = got.cpu().numpy()
+        for i, w in enumerate(want):
+            assert got[i].tobytes() == w, cases[i]
+    finally:
+        eng.close()
+

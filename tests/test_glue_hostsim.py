@@ -169,4 +169,5 @@ def test_bam_test_bodies(hostsim, orc, monkeypatch):
     t.test_assembly_and_encode_match_oracle(orc, 0, [1])
     t.test_assembly_and_encode_match_oracle(orc, 2, [300, 5, 257])
     t.test_decoder_flags_malformed_records(orc)
+    t.test_slice_md5_matches_hashlib(orc)
 
