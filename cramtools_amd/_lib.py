@@ -169,6 +169,8 @@ SYMBOLS = {
     "cramgpu_bam_decode_dev": (I32, [P, I32, P, P, P, P, P]),
     "cramgpu_bam_index": (I64, [P, I64, P, I64]),
     "cramgpu_slice_md5_dev": (I32, [P, I32, P, P, P, P, P, P]),
+    "cramgpu_gunzip_dev": (I32, [P, P, P, P, I32, P, P]),
+    "cramgpu_bgzf_index": (I64, [P, I64, P, P, I64]),
     "cramgpu_ref_upload": (I32, [P, I32, P, I64]),
     "cramgpu_ref_drop": (I32, [P, I32]),
     "cramgpu_submit_reads": (P, [P, P, C.c_char_p, I32, P]),

@@ -1055,6 +1055,45 @@ int32_t cramgpu_slice_md5_dev(cramgpu_ctx* c, int32_t n_slices, const uint8_t* d
     return 0;
 }
 
+int32_t cramgpu_gunzip_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks, int32_t n,
+                           int32_t* d_out_len, void* stream) {
+    if (!c || n < 0 || (n > 0 && (!d_in || !d_out || !d_blocks || !d_out_len))) return fail(CRAMGPU_E_ARG, "gunzip: bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(launch_gunzip(d_in, d_out, d_blocks, n, d_out_len, s));
+    return 0;
+}
+
+int64_t cramgpu_bgzf_index(const uint8_t* data, int64_t len, int64_t* off, int32_t* usize, int64_t cap) {
+    if (!data || len < 0 || (cap > 0 && (!off || !usize))) return fail(CRAMGPU_E_ARG, "bgzf_index: bad argument");
+    int64_t at = 0, n = 0;
+    while (at < len) {  // SAM specification 4.1: gzip member with FEXTRA, subfield 'B' 'C' of 2 bytes = BSIZE (size - 1)
+        if (at + 18 > len || data[at] != 0x1F || data[at + 1] != 0x8B || data[at + 2] != 8 || !(data[at + 3] & 4))
+            return fail(CRAMGPU_E_CORRUPT, "bgzf_index: not a BGZF block header");
+        const int64_t xlen = (int64_t)data[at + 10] | (int64_t)data[at + 11] << 8;
+        if (at + 12 + xlen > len) return fail(CRAMGPU_E_CORRUPT, "bgzf_index: extra field runs past the end");
+        int64_t bsize = -1;
+        for (int64_t q = at + 12; q + 4 <= at + 12 + xlen;) {
+            const int64_t slen = (int64_t)data[q + 2] | (int64_t)data[q + 3] << 8;
+            if (data[q] == 'B' && data[q + 1] == 'C' && slen == 2 && q + 6 <= at + 12 + xlen)
+                bsize = ((int64_t)data[q + 4] | (int64_t)data[q + 5] << 8) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || at + bsize > len) return fail(CRAMGPU_E_CORRUPT, "bgzf_index: bad block size");
+        if (n < cap) {
+            off[n] = at;
+            const uint8_t* t = data + at + bsize - 4;
+            usize[n] = (int32_t)((uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24);
+        }
+        n++;
+        at += bsize;
+    }
+    if (n < cap) off[n] = at;
+    return n;
+}
+
 int64_t cramgpu_bam_index(const uint8_t* bam, int64_t len, int64_t* rec_off, int64_t cap) {
     if (!bam || len < 0 || (cap > 0 && !rec_off)) return fail(CRAMGPU_E_ARG, "bam_index: bad argument");
     int64_t at = 0, n = 0;

@@ -143,6 +143,40 @@ class Engine:
         _lib.check(_lib.lib().cramgpu_rans_decode_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), C.addressof(blocks), n,
                                                       d_out_len.data_ptr(), s))
 
+    def gunzip_dev(self, d_in, d_out, d_blocks, n, d_out_len, stream=None):
+        """ExternalCompression#gunzip for n streams at once (cramgpu_gunzip_dev): d_blocks = DEVICE tensor holding n
+        cramgpu_block descriptors (BLOCK dtype bytes)."""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().cramgpu_gunzip_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), d_blocks.data_ptr(), n,
+                                                 d_out_len.data_ptr(), s))
+
+    def gunzip_many(self, datas, raw_sizes, device="cuda:0"):
+        """[gzip bytes], [raw size] -> [bytes]; raises CramGpuError for the first stream that fails."""
+        import torch
+        n = len(datas)
+        if n == 0:
+            return []
+        desc = (_lib.Block * n)()
+        in_off = out_off = 0
+        for i, d in enumerate(datas):
+            desc[i] = _lib.Block(in_off, out_off, len(d), int(raw_sizes[i]), 0, 0)
+            in_off += len(d)
+            out_off += int(raw_sizes[i])
+        d_in = torch.as_tensor(np.frombuffer(b"".join(bytes(d) for d in datas) + bytes(16), np.uint8).copy()).to(device)
+        d_out = torch.zeros(out_off + 16, dtype=torch.uint8, device=device)
+        d_desc = torch.as_tensor(np.frombuffer(bytes(desc), np.uint8).copy()).to(device)
+        d_len = torch.zeros(n, dtype=torch.int32, device=device)
+        self.gunzip_dev(d_in, d_out, d_desc, n, d_len)
+        lens = d_len.cpu().numpy()
+        out = d_out.cpu().numpy()
+        res = []
+        for i in range(n):
+            if lens[i] < 0:
+                raise CramGpuError(int(lens[i]), "gzip stream %d" % i)
+            res.append(out[desc[i].out_off:desc[i].out_off + int(lens[i])].tobytes())
+        return res
+
     def gather_dev(self, d_src, d_pos, d_len, n, max_len, d_dst, d_dst_off, align=16, stream=None):
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream

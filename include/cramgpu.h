@@ -498,6 +498,27 @@ int32_t cramgpu_bam_decode_dev(cramgpu_ctx* ctx, int32_t n_reads, const uint8_t*
  * end: SAMFormatException "Invalid record length"). */
 int64_t cramgpu_bam_index(const uint8_t* bam, int64_t len, int64_t* rec_off, int64_t cap);
 
+/* =====================================================================================================
+ * gunzip (the decode halves): htsjdk!io/ExternalCompression#gunzip (L41-48, a
+ * java.util.zip.GZIPInputStream read to its end) as htsjdk!structure/Block#uncompress (L228-262) calls it for the GZIP
+ * external blocks of a container, and the BGZF blocks of a BAM file (SAM specification §4.1; htsjdk!util/
+ * BlockCompressedInputStream in front of Bam_OBA_Supplier).  RFC 1952 members (several in a row are read through, as
+ * GZIPInputStream does; bytes behind the last member that are no header are ignored), RFC 1951 data, CRC-32 and ISIZE
+ * checked.  Compression stays with the host (byte identity with zlib level 5 is outside the parity contract).
+ * ===================================================================================================== */
+
+/* Stream k = d_in[in_off, in_off + in_len) of d_blocks[k] (a DEVICE array; offsets need no alignment, `order` is ignored)
+ * is inflated to d_out + out_off, at most out_cap bytes (the block header's raw size).  d_out_len[k] = bytes written, or
+ * CRAMGPU_E_CORRUPT (no gzip header, invalid DEFLATE data, a stream that ends early, CRC-32 / ISIZE mismatch: the
+ * ZipException / EOFException cases) or CRAMGPU_E_OUT_TOO_SMALL.  Stream-ordered, does not synchronise. */
+int32_t cramgpu_gunzip_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks,
+                           int32_t n_blocks, int32_t* d_out_len, void* stream);
+
+/* Host: the BGZF blocks of a file image — off[cap] (off[n] = len when n < cap) and the uncompressed size of every block
+ * (its ISIZE), from the 'BC' subfield of the headers; nothing is inflated.  Returns the number of blocks or
+ * CRAMGPU_E_CORRUPT. */
+int64_t cramgpu_bgzf_index(const uint8_t* data, int64_t len, int64_t* off, int32_t* usize, int64_t cap);
+
 /* Q1 result — htsjdk!lossy/PreservationPolicy as a POD (parsed on the host by the caller, see
  * src/main/java/htsjdk/samtools/cram/lossy/QualityScorePreservation.java:167-256). */
 typedef struct {

@@ -171,3 +171,12 @@ def test_bam_test_bodies(hostsim, orc, monkeypatch):
     t.test_decoder_flags_malformed_records(orc)
     t.test_slice_md5_matches_hashlib(orc)
 
+
+def test_gunzip_test_bodies(hostsim, monkeypatch):
+    """tests/test_gunzip_gpu.py on the host build of csrc/inflate.hip."""
+    import test_gunzip_gpu as t
+    monkeypatch.setattr(t, "DEV", "cpu")
+    t.test_gunzip_matches_zlib()
+    t.test_bgzf_blocks()
+    t.test_gunzip_failures()
+
