@@ -7,10 +7,12 @@
 // a function: any conforming inflater returns the same bytes, so parity is byte equality with zlib.
 //
 // Shape on the machine: DEFLATE is one serial bit stream per member — the parallelism is across members (a BAM file is
-// tens of thousands of BGZF blocks, a batch of containers thousands of gzip series).  A lane per stream: 64 streams share
-// one instruction stream, each with its own canonical Huffman tables in LDS (counts per code length + symbols in code
-// order, decoded bit by bit — 0.7 KB per lane, interleaved by lane so that a wave's table reads spread over the banks), a
-// 64-bit bit buffer refilled with unaligned 4-byte loads, matches copied 4 bytes at a time when the distance allows.
+// tens of thousands of BGZF blocks, a batch of containers thousands of gzip series).  A lane per stream: 2 to 16 streams share
+// one wave (few, so that the streams in flight spread over every SIMD and diverge little), each with its own canonical Huffman tables in LDS (counts per code length + symbols in code
+// order — 0.7 KB per lane, interleaved by lane so that a wave's table reads spread over the banks — and in front of them a
+// direct table over the next 10 / 7 bits (symbol and code length in one 16-bit entry: one LDS read per symbol instead of
+// one per code bit; longer codes fall back to the bit-by-bit walk), a 64-bit bit buffer refilled with unaligned 4-byte
+// loads, matches copied 4 bytes at a time when the distance allows.
 // Then CRC-32 of what was written, as GZIPInputStream#readTrailer checks it.
 #include "internal.h"
 
@@ -18,15 +20,18 @@ namespace {
 
 struct __attribute__((packed)) W32u { uint32_t v; };
 
-constexpr int kMaxLanes = 64;
+constexpr int kMaxLanes = 16;
 constexpr int kLitSyms = 288, kDistSyms = 32, kLenCodes = 19;
 // per-lane LDS (u16 entries, interleaved by lane): counts lit [16], counts dist [16], offsets [16], symbols lit [288], dist [32]
 constexpr int kCntL = 0, kCntD = 16, kOffs = 32, kSymL = 48, kSymD = kSymL + kLitSyms, kTabU16 = kSymD + kDistSyms;
 constexpr int kLensBytes = (kLitSyms + kDistSyms) / 2;  // code lengths, a nibble each
+// direct tables: entry = symbol << 4 | code length (0 = a longer code or none: the canonical walk decides)
+constexpr int kFastLBits = 10, kFastDBits = 7;
+constexpr int kFastL = kTabU16, kFastD = kFastL + (1 << kFastLBits), kAllU16 = kFastD + (1 << kFastDBits);
 
 template <int LANES>
 struct InflateLds {
-    uint16_t tab[kTabU16][LANES];
+    uint16_t tab[kAllU16][LANES];
     uint8_t lens[kLensBytes][LANES];
     uint32_t crc[256];
 };
@@ -34,7 +39,7 @@ static_assert(sizeof(InflateLds<kMaxLanes>) <= 64 * 1024, "static LDS of a workg
 
 struct Bits {
     const uint8_t* p;
-    int64_t n, pos;
+    int32_t n, pos;
     unsigned long long buf;
     int cnt;
     bool err;
@@ -53,16 +58,15 @@ __device__ __forceinline__ void refill(Bits& b) {
         }
     }
 }
-__device__ __forceinline__ uint32_t getbits(Bits& b, int k) {  // k <= 16
+__device__ __forceinline__ uint32_t getbits(Bits& b, int k) {  // k <= 16; sets b.err when the stream has fewer bits
     refill(b);
-    if (b.cnt < k) {
-        b.err = true;
-        return 0;
-    }
+    const bool ok = b.cnt >= k;
     const uint32_t v = (uint32_t)b.buf & ((1u << k) - 1u);
-    b.buf >>= k;
-    b.cnt -= k;
-    return v;
+    b.err |= !ok;
+    const int take = ok ? k : 0;
+    b.buf >>= take;
+    b.cnt -= take;
+    return ok ? v : 0u;
 }
 
 template <int LANES>
@@ -77,21 +81,30 @@ struct TablesT {
     }
 };
 
-// canonical code of the lengths lens[first .. first + n): counts per length at cnt0, symbols in code order at sym0.
+// Control flow in this file is kept to loops with ONE exit and sticky error codes instead of early returns: 4 to 16
+// diverging streams share a wave, and every extra way out of a loop nest costs the wave execution-mask bookkeeping on
+// every turn (the first version, written with returns, spent most of its time there).
+
+// canonical code of the lengths lens[first .. first + n): counts per length at cnt0, symbols in code order at sym0, and
+// the direct table over the next `bits` bits at fast0 (canonical code values in symbol order, RFC 1951 §3.2.2, bit-reversed
+// because the stream delivers a code's first bit lowest; bits == 0: none).
 // Returns false for an over-subscribed set, or an incomplete one with more than a single one-bit code (zlib's rule:
 // inftrees.c accepts an incomplete literal / distance code only when its longest code has one bit).
 template <class Tables>
-__device__ bool construct(Tables& T, int first, int n, int cnt0, int sym0, bool strict) {
+__device__ bool construct(Tables& T, int first, int n, int cnt0, int sym0, bool strict, int fast0, int bits) {
     for (int l = 0; l < 16; l++) T.t(cnt0 + l) = 0;
     for (int s = 0; s < n; s++) T.t(cnt0 + T.len_get(first + s))++;
     int left = 1, max_len = 0;
+    bool over = false;
     for (int l = 1; l < 16; l++) {
-        left <<= 1;
-        left -= (int)T.t(cnt0 + l);
-        if (left < 0) return false;
-        if (T.t(cnt0 + l)) max_len = l;
+        const int c = (int)T.t(cnt0 + l);
+        left = (left << 1) - c;
+        over |= left < 0;
+        left = left < 0 ? 0 : left;
+        max_len = c ? l : max_len;
     }
-    if (left > 0 && (strict ? max_len != 0 : max_len > 1)) return false;  // the code-length code must be complete
+    const bool good = !over && !(left > 0 && (strict ? max_len != 0 : max_len > 1));  // the code-length code must be complete
+    // offsets of the symbols per length, then (for the direct table) the next code value per length, in the same 16 cells
     T.t(kOffs + 1) = 0;
     for (int l = 1; l < 15; l++) T.t(kOffs + l + 1) = (uint16_t)(T.t(kOffs + l) + T.t(cnt0 + l));
     for (int s = 0; s < n; s++) {
@@ -102,149 +115,192 @@ __device__ bool construct(Tables& T, int first, int n, int cnt0, int sym0, bool 
             T.t(kOffs + l) = (uint16_t)(o + 1);
         }
     }
-    return true;
+    if (bits > 0 && good) {
+        for (int i = 0; i < (1 << bits); i++) T.t(fast0 + i) = 0;
+        int code = 0;
+        for (int l = 1; l < 16; l++) {  // next_code[l]
+            code = (code + (l > 1 ? (int)T.t(cnt0 + l - 1) : 0)) << 1;
+            T.t(kOffs + l) = (uint16_t)code;
+        }
+        for (int s = 0; s < n; s++) {
+            const int l = T.len_get(first + s);
+            if (l != 0) {
+                const uint32_t c = T.t(kOffs + l);
+                T.t(kOffs + l) = (uint16_t)(c + 1);
+                if (l <= bits) {
+                    const uint16_t e = (uint16_t)((s << 4) | l);
+                    for (uint32_t i = __brev(c) >> (32 - l); i < (1u << bits); i += 1u << l) T.t(fast0 + (int)i) = e;
+                }
+            }
+        }
+    }
+    return good;
 }
 
+// bit-by-bit walk of the canonical code; -1 when the bits run out or no code matches
 template <class Tables>
-__device__ int decode_sym(Bits& b, Tables& T, int cnt0, int sym0) {
+__device__ __forceinline__ int decode_walk(Bits& b, Tables& T, int cnt0, int sym0) {
     refill(b);
-    int code = 0, first = 0, index = 0;
-    for (int l = 1; l < 16; l++) {
+    int code = 0, first = 0, index = 0, sym = -1;
+    bool stop = false;
+#pragma unroll 1
+    for (int l = 1; l < 16 && !stop; l++) {
         if (b.cnt == 0) {
             b.err = true;
-            return -1;
+            stop = true;
+        } else {
+            code |= (int)(b.buf & 1ull);
+            b.buf >>= 1;
+            b.cnt--;
+            const int count = (int)T.t(cnt0 + l);
+            if (code - count < first) {
+                sym = (int)T.t(sym0 + index + (code - first));
+                stop = true;
+            } else {
+                index += count;
+                first = (first + count) << 1;
+                code <<= 1;
+            }
         }
-        code |= (int)(b.buf & 1ull);
-        b.buf >>= 1;
-        b.cnt--;
-        const int count = (int)T.t(cnt0 + l);
-        if (code - count < first) return (int)T.t(sym0 + index + (code - first));
-        index += count;
-        first += count;
-        first <<= 1;
-        code <<= 1;
     }
-    return -1;  // ran out of codes
+    return sym;
 }
 
-// One DEFLATE stream into out[o ..).  Returns 0 or a negative code; o / member start m0 bound the match distances.
 template <class Tables>
-__device__ int inflate_stream(Bits& b, Tables& T, uint8_t* out, int64_t cap, int64_t& o, int64_t m0) {
+__device__ __forceinline__ int decode_fast(Bits& b, Tables& T, int cnt0, int sym0, int fast0, int bits) {
+    refill(b);
+    const uint32_t e = T.t(fast0 + (int)((uint32_t)b.buf & ((1u << bits) - 1u)));
+    const int l = (int)(e & 15u);
+    int sym;
+    if (l != 0 && l <= b.cnt) {
+        b.buf >>= l;
+        b.cnt -= l;
+        sym = (int)(e >> 4);
+    } else {
+        sym = decode_walk(b, T, cnt0, sym0);  // a longer code, an unused pattern, or the last bits of the stream
+    }
+    return sym;
+}
+
+// One DEFLATE stream into out[o ..).  Returns 0 or a negative code; the member start m0 bounds the match distances.
+template <class Tables>
+__device__ int inflate_stream(Bits& b, Tables& T, uint8_t* out, int32_t cap, int32_t& o_io, int32_t m0) {
     static constexpr uint8_t kOrder[kLenCodes] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    for (;;) {
-        const uint32_t last = getbits(b, 1), type = getbits(b, 2);
-        if (b.err) return CRAMGPU_E_CORRUPT;
-        if (type == 0) {  // stored
+    int rc = 0;
+    int32_t o = o_io;
+    bool last = false;
+    while (rc == 0 && !last) {
+        last = getbits(b, 1) != 0;
+        const uint32_t type = getbits(b, 2);
+        if (b.err || type == 3) {
+            rc = CRAMGPU_E_CORRUPT;
+        } else if (type == 0) {  // stored
             b.buf >>= (b.cnt & 7);
             b.cnt -= (b.cnt & 7);
             const uint32_t len = getbits(b, 16), nlen = getbits(b, 16);
-            if (b.err || (len ^ 0xFFFFu) != nlen) return CRAMGPU_E_CORRUPT;
-            if (o + len > cap) return CRAMGPU_E_OUT_TOO_SMALL;
-            for (uint32_t i = 0; i < len; i++) {
-                const uint32_t c = getbits(b, 8);
-                if (b.err) return CRAMGPU_E_CORRUPT;
-                out[o++] = (uint8_t)c;
+            if (b.err || (len ^ 0xFFFFu) != nlen) {
+                rc = CRAMGPU_E_CORRUPT;
+            } else if ((int64_t)o + len > cap) {
+                rc = CRAMGPU_E_OUT_TOO_SMALL;
+            } else {
+                for (uint32_t i = 0; i < len && !b.err; i++) out[o + (int32_t)i] = (uint8_t)getbits(b, 8);
+                o += (int32_t)len;
+                if (b.err) rc = CRAMGPU_E_CORRUPT;
             }
-        } else if (type == 3) {
-            return CRAMGPU_E_CORRUPT;
         } else {
-            int nlen, ndist;
-            if (type == 1) {  // fixed codes (RFC 1951 §3.2.6)
-                nlen = 288, ndist = 32;  // complete sets; the symbols past 285 / 29 are refused when they come up
+            int nlen = 288, ndist = 32;
+            if (type == 1) {  // fixed codes (RFC 1951 §3.2.6): complete sets; symbols past 285 / 29 are refused when they come up
                 for (int s = 0; s < 288; s++) T.len_set(s, s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
                 for (int s = 0; s < 32; s++) T.len_set(kLitSyms + s, 5);
             } else {  // dynamic codes (§3.2.7)
                 nlen = (int)getbits(b, 5) + 257;
                 ndist = (int)getbits(b, 5) + 1;
                 const int ncode = (int)getbits(b, 4) + 4;
-                if (b.err || nlen > 286 || ndist > 30) return CRAMGPU_E_CORRUPT;
                 for (int i = 0; i < kLenCodes; i++) T.len_set(i, 0);
-                for (int i = 0; i < ncode; i++) {
-                    const int v = (int)getbits(b, 3);
-                    T.len_set(kOrder[i], v);
-                }
-                if (b.err) return CRAMGPU_E_CORRUPT;
+                for (int i = 0; i < ncode; i++) T.len_set(kOrder[i], (int)getbits(b, 3));
                 // the code-length code sits in the distance areas while the lengths are read (both are rebuilt below)
-                if (!construct(T, 0, kLenCodes, kCntD, kSymD, true)) return CRAMGPU_E_CORRUPT;
+                if (b.err || nlen > 286 || ndist > 30 || !construct(T, 0, kLenCodes, kCntD, kSymD, true, 0, 0)) rc = CRAMGPU_E_CORRUPT;
                 // the 19 lengths of the code-length code are dead once it is built: the symbol lengths overwrite them
-                int idx = 0;
-                int prev = 0;
-                while (idx < nlen + ndist) {
-                    int sym = decode_sym(b, T, kCntD, kSymD);
-                    if (sym < 0 || b.err) return CRAMGPU_E_CORRUPT;
-                    if (sym < 16) {
-                        T.len_set(idx < nlen ? idx : kLitSyms + (idx - nlen), sym);
-                        prev = sym;
-                        idx++;
-                    } else {
-                        int rep, val = 0;
-                        if (sym == 16) {
-                            if (idx == 0) return CRAMGPU_E_CORRUPT;
-                            val = prev;
-                            rep = 3 + (int)getbits(b, 2);
-                        } else if (sym == 17) {
-                            rep = 3 + (int)getbits(b, 3);
-                        } else {
-                            rep = 11 + (int)getbits(b, 7);
-                        }
-                        if (b.err || idx + rep > nlen + ndist) return CRAMGPU_E_CORRUPT;
+                int idx = 0, prev = 0;
+                const int total = nlen + ndist;
+                while (rc == 0 && idx < total) {
+                    const int sym = decode_walk(b, T, kCntD, kSymD);
+                    int rep = 1, val = sym;
+                    if (sym == 16) {
+                        val = prev;
+                        rep = 3 + (int)getbits(b, 2);
+                        if (idx == 0) rc = CRAMGPU_E_CORRUPT;
+                    } else if (sym == 17) {
+                        val = 0;
+                        rep = 3 + (int)getbits(b, 3);
+                    } else if (sym == 18) {
+                        val = 0;
+                        rep = 11 + (int)getbits(b, 7);
+                    }
+                    if (sym < 0 || b.err || idx + rep > total) rc = CRAMGPU_E_CORRUPT;
+                    if (rc == 0) {
                         for (int q = 0; q < rep; q++, idx++) T.len_set(idx < nlen ? idx : kLitSyms + (idx - nlen), val);
                         prev = val;
                     }
                 }
-                if (T.len_get(256) == 0) return CRAMGPU_E_CORRUPT;  // no end-of-block code
+                if (rc == 0 && T.len_get(256) == 0) rc = CRAMGPU_E_CORRUPT;  // no end-of-block code
             }
-            if (!construct(T, 0, nlen, kCntL, kSymL, false)) return CRAMGPU_E_CORRUPT;
-            if (!construct(T, kLitSyms, ndist, kCntD, kSymD, false)) return CRAMGPU_E_CORRUPT;
-            for (;;) {
-                int sym = decode_sym(b, T, kCntL, kSymL);
-                if (sym < 0 || b.err) return CRAMGPU_E_CORRUPT;
-                if (sym < 256) {
-                    if (o >= cap) return CRAMGPU_E_OUT_TOO_SMALL;
-                    out[o++] = (uint8_t)sym;
-                    continue;
-                }
-                if (sym == 256) break;
-                if (sym > 285) return CRAMGPU_E_CORRUPT;
-                int len;
-                if (sym < 265) {
-                    len = sym - 254;
-                } else if (sym == 285) {
-                    len = 258;
+            if (rc == 0 && !construct(T, 0, nlen, kCntL, kSymL, false, kFastL, kFastLBits)) rc = CRAMGPU_E_CORRUPT;
+            if (rc == 0 && !construct(T, kLitSyms, ndist, kCntD, kSymD, false, kFastD, kFastDBits)) rc = CRAMGPU_E_CORRUPT;
+            bool eob = false;
+            while (rc == 0 && !eob) {
+                const int sym = decode_fast(b, T, kCntL, kSymL, kFastL, kFastLBits);
+                if (sym < 0 || sym > 285) {
+                    rc = CRAMGPU_E_CORRUPT;
+                } else if (sym < 256) {
+                    if (o >= cap) {
+                        rc = CRAMGPU_E_OUT_TOO_SMALL;
+                    } else {
+                        out[o] = (uint8_t)sym;
+                        o++;
+                    }
+                } else if (sym == 256) {
+                    eob = true;
                 } else {
-                    const int e = (sym - 261) >> 2;
-                    len = ((4 + ((sym - 261) & 3)) << e) + 3 + (int)getbits(b, e);
+                    int len = sym - 254;  // 257..264
+                    if (sym == 285) {
+                        len = 258;
+                    } else if (sym >= 265) {
+                        const int e = (sym - 261) >> 2;
+                        len = ((4 + ((sym - 261) & 3)) << e) + 3 + (int)getbits(b, e);
+                    }
+                    const int ds = decode_fast(b, T, kCntD, kSymD, kFastD, kFastDBits);
+                    int32_t dist = ds + 1;  // 0..3
+                    if (ds >= 4 && ds <= 29) {
+                        const int e = (ds >> 1) - 1;  // <= 13
+                        dist = ((2 + (ds & 1)) << e) + 1 + (int32_t)getbits(b, e);
+                    }
+                    if (ds < 0 || ds > 29 || b.err || dist > o - m0) {
+                        rc = CRAMGPU_E_CORRUPT;
+                    } else if ((int64_t)o + len > cap) {
+                        rc = CRAMGPU_E_OUT_TOO_SMALL;
+                    } else {
+                        uint8_t* d = out + o;
+                        const uint8_t* s = d - dist;
+                        int i = 0;
+                        if (dist >= 4)
+                            for (; i + 4 <= len; i += 4) reinterpret_cast<W32u*>(d + i)->v = reinterpret_cast<const W32u*>(s + i)->v;
+                        for (; i < len; i++) d[i] = s[i];
+                        o += len;
+                    }
                 }
-                const int ds = decode_sym(b, T, kCntD, kSymD);
-                if (ds < 0 || ds > 29 || b.err) return CRAMGPU_E_CORRUPT;
-                int64_t dist;
-                if (ds < 4) {
-                    dist = ds + 1;
-                } else {
-                    const int e = (ds >> 1) - 1;
-                    uint32_t x = e > 16 ? 0u : getbits(b, e);  // e <= 13
-                    dist = ((int64_t)(2 + (ds & 1)) << e) + 1 + x;
-                }
-                if (b.err || dist > o - m0) return CRAMGPU_E_CORRUPT;
-                if (o + len > cap) return CRAMGPU_E_OUT_TOO_SMALL;
-                uint8_t* d = out + o;
-                const uint8_t* s = d - dist;
-                int i = 0;
-                if (dist >= 4)
-                    for (; i + 4 <= len; i += 4) reinterpret_cast<W32u*>(d + i)->v = reinterpret_cast<const W32u*>(s + i)->v;
-                for (; i < len; i++) d[i] = s[i];
-                o += len;
             }
         }
-        if (last) return 0;
     }
+    o_io = o;
+    return rc;
 }
 
-// LANES streams per workgroup (one wave, LANES of its lanes at work): few streams are spread over many waves so that every
-// SIMD has some — a lane's chain of table reads and loads is latency, and 64 diverging streams in one wave serialise
+// LANES streams per workgroup (one wave, LANES of its lanes at work): the streams in flight are spread over many waves so
+// that every SIMD has some, and few streams diverge inside a wave
 template <int LANES>
 __global__ __launch_bounds__(LANES) void gunzip_kernel(const uint8_t* in, uint8_t* out, const cramgpu_block* desc, int32_t n,
-                                                       int32_t* out_len, int exp) {
+                                                       int32_t* out_len) {
     __shared__ InflateLds<LANES> lds;
     for (int i = threadIdx.x; i < 256; i += LANES) {  // CRC-32 (IEEE 802.3, reflected 0xEDB88320) byte table
         uint32_t c = (uint32_t)i;
@@ -253,81 +309,92 @@ __global__ __launch_bounds__(LANES) void gunzip_kernel(const uint8_t* in, uint8_
     }
     __syncthreads();
     const int32_t k = (int32_t)(blockIdx.x * LANES + threadIdx.x);
-    if (k >= n) return;
-    const cramgpu_block D = desc[k];
-    TablesT<LANES> T{&lds, (int)threadIdx.x};
-    Bits b{in + D.in_off, D.in_len, 0, 0ull, 0, false};
-    uint8_t* o_base = out + D.out_off;
-    const int64_t cap = D.out_cap;
-    int64_t o = 0;
-    int rc = 0;
-    bool any = false;
-    while (rc == 0) {
-        // member header (RFC 1952 §2.3); after the first member anything that is not a header ends the stream quietly,
-        // as GZIPInputStream#readTrailer does
-        const int64_t h = b.pos;
-        const uint8_t* p = b.p + h;
-        const int64_t left = b.n - h;
-        if (left < 18 || p[0] != 0x1F || p[1] != 0x8B || p[2] != 8) {
-            if (!any) rc = CRAMGPU_E_CORRUPT;
-            break;
-        }
-        const int flg = p[3];
-        int64_t q = 10;
-        if (flg & 4) {
-            if (q + 2 > left) { rc = any ? 1 : CRAMGPU_E_CORRUPT; break; }
-            q += 2 + ((int64_t)p[q] | (int64_t)p[q + 1] << 8);
-        }
-        for (int f = 8; f <= 16 && q <= left; f <<= 1)
-            if (flg & f) {
-                while (q < left && p[q] != 0) q++;
-                q++;
+    if (k < n) {
+        const cramgpu_block D = desc[k];
+        TablesT<LANES> T{&lds, (int)threadIdx.x};
+        Bits b{in + D.in_off, D.in_len, 0, 0ull, 0, false};
+        uint8_t* o_base = out + D.out_off;
+        const int32_t cap = D.out_cap;
+        int32_t o = 0;
+        int rc = 0;  // 0 go on, 1 done, < 0 failed
+        bool any = false;
+        while (rc == 0) {
+            // member header (RFC 1952 §2.3); after the first member anything that is not a header ends the stream quietly,
+            // as GZIPInputStream#readTrailer does
+            const int32_t h = b.pos;
+            const uint8_t* p = b.p + h;
+            const int32_t left = b.n - h;
+            const int stop = any ? 1 : CRAMGPU_E_CORRUPT;
+            int32_t q = 10;
+            if (left < 18 || p[0] != 0x1F || p[1] != 0x8B || p[2] != 8) {
+                rc = stop;
+            } else {
+                const int flg = p[3];
+                if (flg & 4) q += 2 + ((int32_t)p[10] | (int32_t)p[11] << 8);
+                for (int f = 8; f <= 16; f <<= 1)
+                    if (flg & f) {
+                        while (q < left && p[q] != 0) q++;
+                        q++;
+                    }
+                if (flg & 2) q += 2;
+                if (q + 8 > left) rc = stop;
             }
-        if (flg & 2) q += 2;
-        if (q + 8 > left) { rc = any ? 1 : CRAMGPU_E_CORRUPT; break; }
-        b.pos = h + q;
-        b.buf = 0ull, b.cnt = 0, b.err = false;
-        const int64_t m0 = o;
-        rc = inflate_stream(b, T, o_base, cap, o, m0);
-        if (rc != 0) break;
-        // trailer: the bytes still in the bit buffer go back
-        b.pos -= b.cnt >> 3;
-        b.buf = 0ull, b.cnt = 0;
-        if (b.pos + 8 > b.n) { rc = CRAMGPU_E_CORRUPT; break; }
-        const uint8_t* t = b.p + b.pos;
-        const uint32_t want_crc = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
-        const uint32_t want_len = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
-        b.pos += 8;
-        uint32_t c = 0xFFFFFFFFu;
-        if (!(exp & 1)) for (int64_t i = m0; i < o; i++) c = lds.crc[(c ^ o_base[i]) & 255u] ^ (c >> 8);
-        if ((!(exp & 1) && (c ^ 0xFFFFFFFFu) != want_crc) || (uint32_t)(o - m0) != want_len) { rc = CRAMGPU_E_CORRUPT; break; }
-        any = true;
+            if (rc == 0) {
+                b.pos = h + q;
+                b.buf = 0ull, b.cnt = 0, b.err = false;
+                const int32_t m0 = o;
+                rc = inflate_stream(b, T, o_base, cap, o, m0);
+                if (rc == 0) {
+                    // trailer: the bytes still in the bit buffer go back
+                    b.pos -= b.cnt >> 3;
+                    b.buf = 0ull, b.cnt = 0;
+                    if (b.pos + 8 > b.n) {
+                        rc = CRAMGPU_E_CORRUPT;
+                    } else {
+                        const uint8_t* t = b.p + b.pos;
+                        const uint32_t want_crc = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+                        const uint32_t want_len = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
+                        b.pos += 8;
+                        uint32_t c = 0xFFFFFFFFu;
+                        int32_t i = m0;
+                        for (; i + 4 <= o; i += 4) {
+                            uint32_t w = reinterpret_cast<const W32u*>(o_base + i)->v;
+#pragma unroll
+                            for (int z = 0; z < 4; z++, w >>= 8) c = lds.crc[(c ^ w) & 255u] ^ (c >> 8);
+                        }
+                        for (; i < o; i++) c = lds.crc[(c ^ o_base[i]) & 255u] ^ (c >> 8);
+                        if ((c ^ 0xFFFFFFFFu) != want_crc || (uint32_t)(o - m0) != want_len) rc = CRAMGPU_E_CORRUPT;
+                        any = true;
+                    }
+                }
+            }
+        }
+        out_len[k] = rc < 0 ? rc : o;
     }
-    out_len[k] = rc < 0 ? rc : (int32_t)o;
 }
 
 }  // namespace
 
 hipError_t launch_gunzip(const uint8_t* in, uint8_t* out, const cramgpu_block* d_desc, int32_t n, int32_t* out_len, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    static const int exp = [] {
-        const char* e = getenv("CRAMGPU_GUNZIP_EXP");
-        return e ? atoi(e) : 0;
-    }();
     static const int forced = [] {
         const char* e = getenv("CRAMGPU_GUNZIP_LANES");
         return e ? atoi(e) : 0;
     }();
-    // about four waves per SIMD (4096 waves) before a wave takes more streams
-    const int lanes = forced ? forced : n >= 64 * 4096 ? 64 : n >= 32 * 4096 ? 32 : n >= 16 * 4096 ? 16 : n >= 8 * 4096 ? 8 : 4;
+    // A stream is a chain of dependent table reads and branches (~1200 cycles per symbol): throughput = streams in
+    // flight / that latency.  A CU holds 32 waves, so the fewest streams per wave that still put (nearly) every stream
+    // in flight at once win — 20 000 BGZF blocks: 2 per wave 81 ms, 1 per wave 88 ms (2.4 rounds), 4: 101, 8: 127, 16: 138.
+    int lanes = 2;
+    while (lanes < 16 && (n + lanes - 1) / lanes > 12288) lanes <<= 1;
+    if (forced == 2 || forced == 4 || forced == 8 || forced == 16) lanes = forced;
 #define GUNZIP_LAUNCH(L) \
-    hipLaunchKernelGGL(gunzip_kernel<L>, dim3((unsigned)((n + L - 1) / L)), dim3(L), 0, s, in, out, d_desc, n, out_len, exp)
+    hipLaunchKernelGGL(gunzip_kernel<L>, dim3((unsigned)((n + L - 1) / L)), dim3(L), 0, s, in, out, d_desc, n, out_len)
     switch (lanes) {
-        case 64: GUNZIP_LAUNCH(64); break;
-        case 32: GUNZIP_LAUNCH(32); break;
         case 16: GUNZIP_LAUNCH(16); break;
         case 8: GUNZIP_LAUNCH(8); break;
-        default: GUNZIP_LAUNCH(4); break;
+
+        case 4: GUNZIP_LAUNCH(4); break;
+        default: GUNZIP_LAUNCH(2); break;
     }
 #undef GUNZIP_LAUNCH
     return hipGetLastError();

@@ -139,6 +139,12 @@ inline unsigned long long __ballot(bool p) {
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline unsigned __brev(unsigned v) {
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(v);
+}
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
 inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
