@@ -251,8 +251,9 @@ class Step:
 class DecodeStep:
     """configs[2]: the decode hot path over the streams one encode step produced (nothing allocated while timed):
       K2  rANS decode of every external block (from the gathered dense arena back into a raw arena),
+      G   gunzip of the series the reference stores as GZIP blocks (ExternalCompression#gunzip),
       R   the data-series reader (CramRecordReader#read): the decoded rANS series, and the series the reference gzips
-          taken raw from the writer's arena as the host would hand them over, back into record columns, features, I / S
+          from where G inflates them, back into record columns, features, I / S
           bytes and quality arrays,
       N1  CramNormalizer.restoreReadBases for every read from the READER's columns and features (whole-reference window
           per container, matrices on the host as the compression header holds them),
@@ -291,8 +292,8 @@ class DecodeStep:
         else:  # the round-1 form: columns and features of the encode side
             self.bases = torch.zeros(reads.bases.numel() + 16, dtype=torch.uint8, device=dev)
             self.rflags = reads.rflags | 16  # CRAMGPU_RF_FORCE_QS: lossless records carry CF_FORCE_PRESERVE_QS
-        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        self.k2_ms, self.ms, self.bam_ms = [], [], []
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        self.k2_ms, self.ms, self.bam_ms, self.gz_ms = [], [], [], []
 
     def run(self, timed=True):
         w, L, reads = self.w, _lib.lib(), self.w["reads"]
@@ -302,6 +303,14 @@ class DecodeStep:
         self.eng.decode_dev(self.enc.d_pack, self.d_raw, self.blocks, w["n_blocks"], self.d_len)
         if timed:
             self.ev[1].record()
+        gz = self.reader is not None and getattr(self, "n_gz", 0)
+        if gz:
+            # behind K2 on the same stream: on a stream of its own beside K2 it gains nothing (measured both launch orders:
+            # the two kernels do not share the chip, the leg takes 57 ms either way)
+            self.eng.gunzip_dev(self.d_gz, self.d_gz_raw, self.d_gz_desc, self.n_gz, self.d_gz_len,
+                                stream=None if str(self.dev).startswith("cuda") else 0)
+        if timed:
+            self.ev[4].record()
         if self.reader is not None:
             rd = self.reader
             rd.read(self.arena_base, self.r_off, self.r_len, self.cont_first, self.series_bytes, multiref=self.multiref,
@@ -331,6 +340,8 @@ class DecodeStep:
             self.ev[2].record()
             torch.cuda.synchronize()
             self.k2_ms.append(self.ev[0].elapsed_time(self.ev[1]))
+            if gz:
+                self.gz_ms.append(self.ev[1].elapsed_time(self.ev[4]))
             self.ms.append(self.ev[0].elapsed_time(self.ev[2]))
 
     def assemble(self, timed=True):
@@ -375,6 +386,39 @@ class DecodeStep:
             r_off = off.copy()
             in_off = np.array([w["blocks"][i].in_off for i in range(w["n_blocks"])], np.int64).reshape(w["n_cont"], ns)
             r_off[:, self.enc.ids] = self.d_raw.data_ptr() + in_off - base
+            # the other series are GZIP blocks in a CRAM file (ExternalCompression#gzip, level 5: the host's job on encode):
+            # deflated here once at set-up, inflated on the device inside the timed leg (G), read by R from where G puts them
+            import zlib
+            rest = [k for k in range(off.shape[1]) if k not in set(self.enc.ids.tolist())]
+            arena_h = wr.arena.cpu().numpy()
+            gz, desc, in_at, out_at = [], [], 0, 0
+            self.gz_slots = []
+            for c in range(w["n_cont"]):
+                for k in rest:
+                    n_raw = int(ln[c, k])
+                    if n_raw == 0:
+                        continue
+                    co = zlib.compressobj(5, zlib.DEFLATED, 31)
+                    z = co.compress(arena_h[int(off[c, k]):int(off[c, k]) + n_raw].tobytes()) + co.flush()
+                    gz.append(z)
+                    desc.append((in_at, out_at, len(z), n_raw))
+                    self.gz_slots.append((c, k))
+                    in_at += len(z)
+                    out_at += (n_raw + 31) & ~15  # 16 readable bytes behind every stream, as the reader asks
+            self.n_gz = len(gz)
+            if self.n_gz:
+                blocks = (_lib.Block * self.n_gz)()
+                for i, (a_, b_, c_, d_) in enumerate(desc):
+                    blocks[i] = _lib.Block(a_, b_, c_, d_, 0, 0)
+                    r_off[self.gz_slots[i][0], self.gz_slots[i][1]] = 0  # set below, once d_gz_raw exists
+                self.d_gz = torch.as_tensor(np.frombuffer(b"".join(gz) + bytes(16), np.uint8).copy()).to(self.dev)
+                self.d_gz_raw = torch.zeros(out_at + 16, dtype=torch.uint8, device=self.dev)
+                self.d_gz_desc = torch.as_tensor(np.frombuffer(bytes(blocks), np.uint8).copy()).to(self.dev)
+                self.d_gz_len = torch.zeros(self.n_gz, dtype=torch.int32, device=self.dev)
+                self.gz_raw_len = np.array([d[3] for d in desc], np.int32)
+                self.gz_bytes = (in_at, int(self.gz_raw_len.sum()))
+                for i, (a_, b_, c_, d_) in enumerate(desc):
+                    r_off[self.gz_slots[i][0], self.gz_slots[i][1]] = self.d_gz_raw.data_ptr() + b_ - base
             self.arena_base = base
             self.r_off = torch.as_tensor(r_off.reshape(-1)).to(self.dev)
             self.r_len = torch.as_tensor(ln.reshape(-1).copy()).to(self.dev)
@@ -399,6 +443,8 @@ class DecodeStep:
         assert int((self.st_b != 0).sum().item()) == 0, "restoreReadBases reported a status"
         assert int((self.st_q != 0).sum().item()) == 0, "restoreQualityScores reported a status"
         if self.reader is not None:
+            if getattr(self, "n_gz", 0):
+                assert np.array_equal(self.d_gz_len.cpu().numpy(), self.gz_raw_len), "a GZIP block failed to inflate"
             rd = self.reader.check()
             assert torch.equal(rd.read_len, reads.read_len) and torch.equal(rd.aln_start, reads.aln_start), "RL / AP"
             assert torch.equal(rd.base_off[:-1], reads.base_off), "record offsets"
@@ -700,7 +746,7 @@ def main(argv=None, backend_factory=GpuBackend):
         dec = be.decode_step(w, step)
         dec.prepare()
         dec.run()
-        dec.k2_ms, dec.ms = [], []
+        dec.k2_ms, dec.ms, dec.gz_ms = [], [], []
         dt_dec = sharding.timed_region(dec.run, a.steps, dist=dist, sync=be.sync)
         dec_parity = dec.verify()
         if getattr(dec, "reader", None) is not None:  # container assembly + BAM records on the restored reads
@@ -734,11 +780,18 @@ def main(argv=None, backend_factory=GpuBackend):
                                  algorithmic_bytes=algo)
         if dec is not None:
             k2_s, dec_s = float(np.mean(dec.k2_ms)) / 1e3, dt_dec / a.steps
-            extra["decode"] = dict(workload="configs[2]: rANS decode of the same %d blocks + restoreReadBases / "
-                                            "restoreQualityScores of the %d reads per rank (timed outside the K steps, barrier "
+            extra["decode"] = dict(workload="configs[2]: rANS decode of the same %d blocks + gunzip of the GZIP series + the "
+                                            "data-series reader + restoreReadBases / restoreQualityScores of the %d reads per rank (timed outside the K steps, barrier "
                                             "and MAX over ranks like them)" % (w["n_blocks"], a.reads),
                                    value=w["raw_bytes"] * world / dec_s / 1e6, unit="MB/s", reads_per_s=a.reads * world / dec_s,
                                    ms_per_step=dec_s * 1e3, rans_decode_kernel_ms=k2_s * 1e3,
+                                   ms_per_step_without_gunzip=(dec_s * 1e3 - float(np.mean(dec.gz_ms))
+                                                               if getattr(dec, "n_gz", 0) else dec_s * 1e3),
+                                   gunzip=(dict(ms=float(np.mean(dec.gz_ms)), streams=dec.n_gz, gz_bytes=dec.gz_bytes[0],
+                                                raw_bytes=dec.gz_bytes[1],
+                                                note="the series the reference stores as GZIP blocks, inflated on the device "
+                                                     "inside the leg (zlib level 5 made them at set-up)")
+                                           if getattr(dec, "n_gz", 0) else None),
                                    rans_decode_GBps=algo / k2_s / 1e9, rans_decode_frac_of_hbm=algo / k2_s / 1e9 / HBM_PEAK_GBS,
                                    parity=dec_parity)
             if getattr(dec, "bam_ms", None):

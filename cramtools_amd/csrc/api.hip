@@ -1058,11 +1058,11 @@ int32_t cramgpu_slice_md5_dev(cramgpu_ctx* c, int32_t n_slices, const uint8_t* d
 int32_t cramgpu_gunzip_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks, int32_t n,
                            int32_t* d_out_len, void* stream) {
     if (!c || n < 0 || (n > 0 && (!d_in || !d_out || !d_blocks || !d_out_len))) return fail(CRAMGPU_E_ARG, "gunzip: bad argument");
+    // no scratch of the context is touched: the launch is not ordered against the context's other calls, so a caller may
+    // run it on a stream of its own beside them (e.g. beside the rANS decode of the same container batch)
     std::lock_guard<std::mutex> lk(c->mu);
-    hipStream_t s = pick(c, stream);
-    if (int rc = enter(c, s)) return rc;
-    CallScope scope{c, s};
-    HIPCHK(launch_gunzip(d_in, d_out, d_blocks, n, d_out_len, s));
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(launch_gunzip(d_in, d_out, d_blocks, n, d_out_len, pick(c, stream)));
     return 0;
 }
 

@@ -283,9 +283,23 @@ __device__ int inflate_stream(Bits& b, Tables& T, uint8_t* out, int32_t cap, int
                         uint8_t* d = out + o;
                         const uint8_t* s = d - dist;
                         int i = 0;
-                        if (dist >= 4)
+                        if (dist >= 4) {
                             for (; i + 4 <= len; i += 4) reinterpret_cast<W32u*>(d + i)->v = reinterpret_cast<const W32u*>(s + i)->v;
-                        for (; i < len; i++) d[i] = s[i];
+                            for (; i < len; i++) d[i] = s[i];
+                        } else {
+                            // a run of period 1..3 (constant series deflate to these): the period is read once and the run
+                            // is stored from registers — a byte-by-byte copy would read back every byte it has just stored
+                            uint32_t pat = s[0];
+                            if (dist > 1) pat |= (uint32_t)s[1] << 8;
+                            if (dist > 2) pat |= (uint32_t)s[2] << 16;
+                            if (dist == 3) {
+                                for (; i < len; i++) d[i] = (uint8_t)(pat >> (8 * (i % 3)));
+                            } else {
+                                const uint32_t w = dist == 1 ? pat * 0x01010101u : pat * 0x00010001u;
+                                for (; i + 4 <= len; i += 4) reinterpret_cast<W32u*>(d + i)->v = w;
+                                for (; i < len; i++) d[i] = (uint8_t)(w >> (8 * (i & 3)));
+                            }
+                        }
                         o += len;
                     }
                 }

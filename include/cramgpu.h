@@ -510,7 +510,8 @@ int64_t cramgpu_bam_index(const uint8_t* bam, int64_t len, int64_t* rec_off, int
 /* Stream k = d_in[in_off, in_off + in_len) of d_blocks[k] (a DEVICE array; offsets need no alignment, `order` is ignored)
  * is inflated to d_out + out_off, at most out_cap bytes (the block header's raw size).  d_out_len[k] = bytes written, or
  * CRAMGPU_E_CORRUPT (no gzip header, invalid DEFLATE data, a stream that ends early, CRC-32 / ISIZE mismatch: the
- * ZipException / EOFException cases) or CRAMGPU_E_OUT_TOO_SMALL.  Stream-ordered, does not synchronise. */
+ * ZipException / EOFException cases) or CRAMGPU_E_OUT_TOO_SMALL.  Stream-ordered, does not synchronise; uses no scratch of
+ * the context, so unlike the other calls it is NOT ordered against calls on other streams: it may run beside them. */
 int32_t cramgpu_gunzip_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks,
                            int32_t n_blocks, int32_t* d_out_len, void* stream);
 
