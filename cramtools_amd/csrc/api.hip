@@ -456,7 +456,14 @@ cramgpu_ctx* cramgpu_open(int32_t device_index) {
     // ask for a full share of the CU's LDS so that the dispatcher cannot stack more than dec_wpc decoder waves on one
     // CU while others hold fewer: the launch lasts as long as its slowest (most crowded) chain
     if (env_int("CRAMGPU_DEC_LDS_SHARE", 1)) {
-        c->dec_lds = std::max(c->dec_lds, (size_t)(lds_per_cu / c->dec_wpc - 1024) & ~(size_t)255);
+        // ... minus a reserve for kernels that run beside the decoder on other streams (the gunzip of the same batch's GZIP
+        // series: 7.4 KiB per two streams) — as much as still keeps dec_wpc + 1 shares from fitting a CU
+        size_t share = (size_t)(lds_per_cu / c->dec_wpc - 1024) & ~(size_t)255;
+        const size_t floor_share = ((size_t)lds_per_cu / (c->dec_wpc + 1) + 512) & ~(size_t)255;
+        const size_t reserve = (size_t)std::max(0, env_int("CRAMGPU_DEC_LDS_RESERVE", 24 * 1024));
+        const size_t lean = (((size_t)lds_per_cu - std::min(reserve, (size_t)lds_per_cu / 2)) / c->dec_wpc) & ~(size_t)255;
+        share = std::min(share, std::max(lean, floor_share));
+        c->dec_lds = std::max(c->dec_lds, share);
         // the share is there anyway: the table region takes all of it (ragged order-1 rows of wide alphabets)
         c->dec_tab_bytes = (int)((c->dec_lds - rans_decode_fixed_lds()) & ~(size_t)15);
     }
