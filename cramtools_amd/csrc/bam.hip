@@ -255,8 +255,9 @@ __global__ __launch_bounds__(256) void bam_size_kernel(int32_t n, cramgpu_bam_co
     if (r >= n) return;
     const int64_t ln = B.names ? B.name_off[r + 1] - B.name_off[r] : dec_digits(B.name_base + r);
     const int64_t lt = B.tags ? B.tag_off[r + 1] - B.tag_off[r] : 0;
-    const int64_t L = B.read_len[r];
-    sizes[r] = (int32_t)(36 + ln + 1 + 4 * (int64_t)B.n_cigar[r] + (L + 1) / 2 + L + lt);
+    // a negative length (a corrupt RL value upstream) is laid out as 0 and reported by the write pass
+    const int64_t L = B.read_len[r] > 0 ? B.read_len[r] : 0, nc = B.n_cigar[r] > 0 ? B.n_cigar[r] : 0;
+    sizes[r] = (int32_t)(36 + (ln > 0 ? ln : 0) + 1 + 4 * nc + (L + 1) / 2 + L + (lt > 0 ? lt : 0));
 }
 
 // BAMRecordView.java:360-415: code of a base, 0xFF = IllegalArgumentException
@@ -298,10 +299,12 @@ __global__ __launch_bounds__(256) void bam_write_kernel(int32_t n, cramgpu_bam_c
     }
     uint8_t* p = bam + rec_off[r];
     const int32_t size = (int32_t)(rec_off[r + 1] - rec_off[r]);
-    const int32_t ln = B.names ? (int32_t)(B.name_off[r + 1] - B.name_off[r]) : dec_digits(B.name_base + r);
-    const int32_t lt = B.tags ? (int32_t)(B.tag_off[r + 1] - B.tag_off[r]) : 0;
-    const int32_t L = B.read_len[r], nc = B.n_cigar[r];
-    bool bad = ln + 1 > 255 || nc > 65535;
+    const int32_t ln_raw = B.names ? (int32_t)(B.name_off[r + 1] - B.name_off[r]) : dec_digits(B.name_base + r);
+    const int32_t lt_raw = B.tags ? (int32_t)(B.tag_off[r + 1] - B.tag_off[r]) : 0;
+    const int32_t ln = ln_raw > 0 ? ln_raw : 0, lt = lt_raw > 0 ? lt_raw : 0;
+    bool bad = B.read_len[r] < 0 || B.n_cigar[r] < 0 || ln_raw < 0 || lt_raw < 0;  // laid out as empty (bam_size_kernel), reported
+    const int32_t L = B.read_len[r] > 0 ? B.read_len[r] : 0, nc = B.n_cigar[r] > 0 ? B.n_cigar[r] : 0;
+    bad = bad || ln + 1 > 255 || nc > 65535;
     if (sl == 0) {  // the fixed part: BAMRecordView.java:23-35
         const int32_t bf = B.bam_flags[r];
         const int32_t rid = B.ref_id[r];
