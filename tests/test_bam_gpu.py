@@ -157,3 +157,80 @@ def test_slice_md5_matches_hashlib(orc):
     finally:
         eng.close()
 
+
+
+def test_mates_and_cigars_at_scale(orc):
+    """500 000 records in 50 containers, pairs linked by next-fragment distances (mates 0..40 records downstream, some
+    three-fragment chains, some detached), features on a third of the reads: mate columns, CIGARs and alignment ends equal
+    the oracle's for every record."""
+    from cramtools_amd import bam, external_compression as xc, records
+    rng = np.random.default_rng(77)
+    n_cont, per = 50, 10000
+    n = n_cont * per
+    bf = np.zeros(n, np.int32)
+    cf = np.zeros(n, np.int32)
+    nf = np.zeros(n, np.int32)
+    taken = np.zeros(n, bool)
+    for c in range(n_cont):
+        lo = c * per
+        i = 0
+        while i < per:
+            r = lo + i
+            roll = rng.random()
+            if taken[r] or roll < 0.1:
+                i += 1
+                continue
+            d = int(rng.integers(0, 41))
+            j = r + 1 + d
+            if roll < 0.2:  # detached pair member
+                bf[r], cf[r] = 1 | 64, 2
+            elif j < lo + per and not taken[j]:
+                bf[r] = 1 | 64 | (16 if rng.random() < 0.5 else 0)
+                cf[r], nf[r] = 4, d
+                bf[j] = 1 | 128 | (16 if rng.random() < 0.5 else 0) | (4 if rng.random() < 0.02 else 0)
+                taken[j] = True
+                if rng.random() < 0.05 and j + 3 < lo + per and not taken[j + 3]:  # a third fragment
+                    cf[j], nf[j] = 4, 2
+                    bf[j + 3] = 1 | (16 if rng.random() < 0.5 else 0)
+                    taken[j + 3] = True
+            taken[r] = True
+            i += 1
+    read_len = np.full(n, 100, np.int32)
+    aln_start = (np.sort(rng.integers(1, 1 << 24, n)) + 1).astype(np.int32)
+    k = rng.random(n) < 0.33
+    k &= (bf & 4) == 0
+    nfeat = np.where(k, rng.integers(1, 4, n), 0)
+    off = np.concatenate([[0], np.cumsum(nfeat)]).astype(np.int64)
+    tot = int(off[-1])
+    ops = rng.choice(np.frombuffer(b"XIDSNiQ", np.uint8), tot)
+    rid = np.repeat(np.arange(n), nfeat)
+    pos = (rng.integers(1, 90, tot) + 0).astype(np.int32)
+    order = np.lexsort((pos, rid))
+    pos, ops = pos[order], ops[order]
+    fa = rng.integers(1, 30, tot).astype(np.int32)
+    fb = rng.integers(1, 10, tot).astype(np.int32)
+    feats_h = dict(off=off, op=ops, pos=pos, a=fa, b=fb)
+    cols_h = {c_: np.zeros(n, np.int32) for c_ in bc.sc_cols()}
+    cols_h.update(bam_flags=bf, comp_flags=cf, next_frag=nf, mate_flags=rng.integers(0, 4, n).astype(np.int32),
+                  mate_ref=np.full(n, 9, np.int32), mate_start=np.full(n, 7, np.int32), tlen=np.full(n, 5, np.int32))
+    cont_first = (np.arange(n_cont + 1) * per).astype(np.int32)
+    cont_ref = rng.integers(0, 24, n_cont).astype(np.int32)
+    ref_id = np.repeat(cont_ref, per)
+    want_c = orc.cigars(read_len, aln_start, bf, feats_h)
+    want_m, want_st = orc.restore_mates(cont_first, cols_h, ref_id, aln_start, want_c["aln_end"])
+    assert not want_st.any()
+    eng = xc.Engine(0)
+    try:
+        feats = records.FeatureBatch.from_host(DEV, ops, pos, fa, fb, off)
+        cols = records.RecordColumns(DEV, n, **cols_h)
+        fac = bam.Cram2SamRecordFactory(eng, DEV)
+        n_cigar, cigar_off, cigar, aln_end = fac.cigars(_t(read_len), _t(aln_start), cols.bam_flags, feats)
+        assert np.array_equal(n_cigar.cpu().numpy(), want_c["n_cigar"]) and np.array_equal(aln_end.cpu().numpy(), want_c["aln_end"])
+        assert np.array_equal(cigar.cpu().numpy().view(np.uint32)[:want_c["total"]], want_c["cigar"][:want_c["total"]])
+        st = fac.restore_mates(cols, _t(cont_first), _t(cont_ref), _t(aln_start), aln_end)
+        assert not st.cpu().numpy().any()
+        for k_ in ("next_frag", "mate_flags", "mate_ref", "mate_start", "tlen"):
+            assert np.array_equal(getattr(cols, k_).cpu().numpy(), want_m[k_]), k_
+        assert (want_m["tlen"] != 5).sum() > n // 4  # the chains really were restored
+    finally:
+        eng.close()
