@@ -350,8 +350,13 @@ __global__ __launch_bounds__(LANES) void gunzip_kernel(const uint8_t* in, uint8_
                         while (q < left && p[q] != 0) q++;
                         q++;
                     }
+                if ((flg & 2) && q + 2 <= left) {  // FHCRC: the low 16 bits of the CRC-32 of the header so far (GZIPInputStream#readHeader checks it)
+                    uint32_t hc = 0xFFFFFFFFu;
+                    for (int32_t i = 0; i < q; i++) hc = lds.crc[(hc ^ p[i]) & 255u] ^ (hc >> 8);
+                    if (((hc ^ 0xFFFFFFFFu) & 0xFFFFu) != ((uint32_t)p[q] | (uint32_t)p[q + 1] << 8)) rc = stop;
+                }
                 if (flg & 2) q += 2;
-                if (q + 8 > left) rc = stop;
+                if (rc == 0 && q + 8 > left) rc = stop;
             }
             if (rc == 0) {
                 b.pos = h + q;

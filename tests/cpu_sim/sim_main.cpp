@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE ONLY — runs the kernels of libcramgpu on the CPU (tests/cpu_sim/hip/hip_runtime.h) under
-// AddressSanitizer against the CPU oracle.  Usage: sim_main [rans|records|all]
+// AddressSanitizer against the CPU oracle.  Usage: sim_main [rans|records|gunzip|bam|all]
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -7,6 +7,8 @@
 #include <random>
 #include <string>
 #include <vector>
+
+#include <zlib.h>
 
 #include "../../include/cramgpu.h"
 
@@ -72,6 +74,170 @@ static int check_rans(cramgpu_ctx* c, const std::vector<Bytes>& datas, int order
 
 int run_records(cramgpu_ctx* c);
 
+// ---- gunzip under the sanitizers: every stream and every output slot is a heap block of its exact size, so a read or a
+// write one byte outside is caught; valid streams at every level / strategy, then mutated ones (bit flips, truncation,
+// garbage) must give zlib's verdict: the same bytes, or an error where zlib reports one
+static Bytes gz_make(const Bytes& d, int level, int strategy) {
+    z_stream z{};
+    deflateInit2(&z, level, Z_DEFLATED, 31, 8, strategy);
+    Bytes o(deflateBound(&z, (uLong)d.size()) + 64);
+    z.next_in = const_cast<Bytef*>(d.data());
+    z.avail_in = (uInt)d.size();
+    z.next_out = o.data();
+    z.avail_out = (uInt)o.size();
+    deflate(&z, Z_FINISH);
+    o.resize(z.total_out);
+    deflateEnd(&z);
+    return o;
+}
+static int gz_ref(const Bytes& s0, size_t cap, Bytes& out) {  // zlib's own inflate of one member: 0 ok, -1 error, -2 too small
+    Bytes s = s0;
+    if (s.size() > 3) s[3] &= 0x1F;  // reserved flag bits: zlib refuses them, java.util.zip.GZIPInputStream#readHeader ignores them
+    z_stream z{};
+    inflateInit2(&z, 31);
+    out.assign(cap + 1, 0);
+    z.next_in = const_cast<Bytef*>(s.data());
+    z.avail_in = (uInt)s.size();
+    z.next_out = out.data();
+    z.avail_out = (uInt)out.size();
+    const int r = inflate(&z, Z_FINISH);
+    const size_t got = z.total_out;
+    inflateEnd(&z);
+    if (r == Z_STREAM_END) {
+        if (got > cap) return -2;
+        out.resize(got);
+        return 0;
+    }
+    if ((r == Z_BUF_ERROR || r == Z_OK) && z.avail_out == 0) return -2;
+    return -1;
+}
+static int run_gunzip(cramgpu_ctx* c) {
+    std::mt19937 rng(11);
+    std::vector<Bytes> plain;
+    for (int n : {0, 1, 5, 300, 5000, 40000}) {
+        Bytes a((size_t)n), b((size_t)n), r((size_t)n);
+        for (int i = 0; i < n; i++) a[i] = "ACGT"[rng() & 3], b[i] = (uint8_t)((i / 97) % 3 + 60), r[i] = (uint8_t)rng();
+        plain.push_back(a), plain.push_back(b), plain.push_back(r);
+    }
+    struct Case { Bytes* in; uint8_t* out; size_t cap; int want; Bytes ref; };
+    std::vector<Case> cases;
+    auto add = [&](const Bytes& s, size_t cap) {
+        Case k;
+        k.in = new Bytes(s);
+        k.in->shrink_to_fit();
+        k.cap = cap;
+        k.out = new uint8_t[cap ? cap : 1];
+        k.want = gz_ref(s, cap, k.ref);
+        cases.push_back(std::move(k));
+    };
+    for (const Bytes& d : plain)
+        for (int level : {0, 1, 6, 9})
+            for (int strat : {Z_DEFAULT_STRATEGY, Z_FIXED, Z_HUFFMAN_ONLY, Z_RLE}) {
+                const Bytes s = gz_make(d, level, strat);
+                add(s, d.size());
+                if (d.size() > 4) add(s, d.size() - 1);  // a slot one byte short
+                for (int m = 0; m < 6; m++) {             // mutations
+                    Bytes t = s;
+                    const int kind = (int)(rng() % 4);
+                    if (kind == 0 && t.size() > 12) t[10 + rng() % (t.size() - 10)] ^= (uint8_t)(1u << (rng() & 7));
+                    else if (kind == 1) t.resize(rng() % (t.size() + 1));
+                    else if (kind == 2 && t.size() > 20) for (int q = 0; q < 8; q++) t[10 + rng() % (t.size() - 10)] = (uint8_t)rng();
+                    else if (!t.empty()) t[rng() % t.size()] = (uint8_t)rng();
+                    add(t, d.size() + (rng() % 3) * 7);
+                }
+            }
+    const int n = (int)cases.size();
+    // offsets relative to the first stream / slot; the kernel only adds them to the base pointers
+    std::vector<cramgpu_block> blocks(n);
+    const uint8_t* in0 = cases[0].in->data();
+    uint8_t* out0 = cases[0].out;
+    for (int i = 0; i < n; i++)
+        blocks[i] = cramgpu_block{(int64_t)(cases[i].in->data() - in0), (int64_t)(cases[i].out - out0), (int32_t)cases[i].in->size(),
+                                  (int32_t)cases[i].cap, 0, 0};
+    std::vector<int32_t> lens(n, 12345);
+    if (cramgpu_gunzip_dev(c, in0, out0, blocks.data(), n, lens.data(), nullptr) != 0) { printf("gunzip rc %s\n", cramgpu_last_error()); return 1; }
+    int bad = 0, ok = 0, refused = 0;
+    for (int i = 0; i < n; i++) {
+        const Case& k = cases[i];
+        if (k.want == 0) {
+            if (lens[i] != (int)k.ref.size() || memcmp(k.out, k.ref.data(), k.ref.size())) bad++, printf("gunzip case %d: got %d want %zu bytes\n", i, lens[i], k.ref.size());
+            ok++;
+        } else {
+            // zlib refuses: so must the kernel (too small a slot may surface as either code when the data is also corrupt)
+            if (lens[i] >= 0) {
+                bad++;
+                printf("gunzip case %d: zlib %d, kernel accepted %d bytes; stream:", i, k.want, lens[i]);
+                for (size_t q = 0; q < k.in->size() && q < 40; q++) printf(" %02x", (*k.in)[q]);
+                printf("\n");
+            }
+            refused++;
+        }
+    }
+    for (Case& k : cases) {
+        delete k.in;
+        delete[] k.out;
+    }
+    printf("gunzip: %s (%d streams: %d valid, %d refused)\n", bad ? "FAILED" : "ok", n, ok, refused);
+    return bad != 0;
+}
+
+// ---- BAM stripes with damaged fields: the decoder must flag the record, never read outside the stripe (a heap block of its
+// exact size) or write outside its outputs
+static void put32(Bytes& b, int32_t v) { for (int k = 0; k < 4; k++) b.push_back((uint8_t)(v >> (8 * k))); }
+static int run_bam_fuzz(cramgpu_ctx* c) {
+    std::mt19937 rng(3);
+    int bad = 0;
+    for (int round = 0; round < 60; round++) {
+        const int n = 1 + (int)(rng() % 40);
+        Bytes stripe;
+        std::vector<int64_t> rec_off;
+        for (int r = 0; r < n; r++) {
+            const int L = (int)(rng() % 70), nc = (int)(rng() % 4), ln = 1 + (int)(rng() % 12), lt = (int)(rng() % 9);
+            rec_off.push_back((int64_t)stripe.size());
+            put32(stripe, 32 + ln + 4 * nc + (L + 1) / 2 + L + lt);
+            put32(stripe, (int32_t)(rng() % 25) - 1);
+            put32(stripe, (int32_t)(rng() % 100000));
+            stripe.push_back((uint8_t)ln), stripe.push_back((uint8_t)(rng() % 61));
+            stripe.push_back(0), stripe.push_back(0);
+            stripe.push_back((uint8_t)nc), stripe.push_back(0);
+            stripe.push_back((uint8_t)rng()), stripe.push_back((uint8_t)(rng() & 15));
+            put32(stripe, L), put32(stripe, -1), put32(stripe, -1), put32(stripe, 0);
+            for (int i = 0; i < ln - 1; i++) stripe.push_back((uint8_t)('a' + rng() % 26));
+            stripe.push_back(0);
+            for (int k = 0; k < nc; k++) put32(stripe, (int32_t)(((rng() % 50) << 4) | (rng() % 9)));
+            for (int i = 0; i < (L + 1) / 2 + L + lt; i++) stripe.push_back((uint8_t)rng());
+        }
+        rec_off.push_back((int64_t)stripe.size());
+        for (int m = 0, nm = (int)(rng() % 6); m < nm; m++) {  // damage: any byte but the block sizes
+            const int r = (int)(rng() % n);
+            const int64_t a = rec_off[r] + 4, b = rec_off[r + 1];
+            stripe[(size_t)(a + (int64_t)(rng() % (uint64_t)(b - a)))] = (uint8_t)rng();
+        }
+        uint8_t* heap = new uint8_t[stripe.size()];
+        memcpy(heap, stripe.data(), stripe.size());
+        const int64_t cap_b = (int64_t)stripe.size() * 2 + 16, cap_c = (int64_t)stripe.size() / 4 + 1;
+        std::vector<int32_t> i32[9];
+        for (auto& v : i32) v.assign((size_t)n, 0);
+        std::vector<int64_t> boff((size_t)n + 1), coff((size_t)n + 1), noff((size_t)n), toff((size_t)n);
+        Bytes mapq((size_t)n), rfl((size_t)n), bases((size_t)cap_b), quals((size_t)cap_b);
+        std::vector<uint32_t> cig((size_t)cap_c);
+        std::vector<int32_t> nlen((size_t)n), tlen2((size_t)n), status((size_t)n, 77);
+        cramgpu_bam_out o{};
+        o.ref_id = i32[0].data(), o.aln_start = i32[1].data(), o.mapq = mapq.data(), o.bam_flags = i32[2].data();
+        o.mate_ref = i32[3].data(), o.mate_start = i32[4].data(), o.tlen = i32[5].data(), o.read_len = i32[6].data();
+        o.base_off = boff.data(), o.bases = bases.data(), o.quals = quals.data(), o.bases_cap = cap_b;
+        o.n_cigar = i32[7].data(), o.cigar_off = coff.data(), o.cigar = cig.data(), o.cigar_cap = cap_c;
+        o.aln_span = i32[8].data(), o.rflags = rfl.data(), o.name_off = noff.data(), o.name_len = nlen.data();
+        o.tag_off = toff.data(), o.tag_len = tlen2.data();
+        if (cramgpu_bam_decode_dev(c, n, heap, rec_off.data(), &o, status.data(), nullptr) != 0) bad++;
+        for (int r = 0; r < n; r++)
+            if (status[r] != 0 && status[r] != CRAMGPU_E_CORRUPT && status[r] != CRAMGPU_E_INSUFFICIENT) bad++;
+        delete[] heap;
+    }
+    printf("bam fuzz: %s\n", bad ? "FAILED" : "ok");
+    return bad != 0;
+}
+
 int main(int argc, char** argv) {
     std::string what = argc > 1 ? argv[1] : "all";
     cramgpu_ctx* c = cramgpu_open(0);
@@ -124,6 +290,8 @@ int main(int argc, char** argv) {
         printf("rans: %s (%zu blocks x 2 orders)\n", bad ? "FAILED" : "ok", datas.size());
     }
     if (!bad && (what == "records" || what == "all")) bad |= run_records(c);
+    if (!bad && (what == "gunzip" || what == "all")) bad |= run_gunzip(c);
+    if (!bad && (what == "bam" || what == "all")) bad |= run_bam_fuzz(c);
     cramgpu_close(c);
     return bad;
 }

@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, name=None, extra=None, comment=None):
+def _member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, name=None, extra=None, comment=None, hcrc=None):
     """One RFC 1952 member built by hand around zlib's raw DEFLATE."""
     co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
     body = co.compress(data) + co.flush()
-    flg = (4 if extra is not None else 0) | (8 if name is not None else 0) | (16 if comment is not None else 0)
+    flg = (4 if extra is not None else 0) | (8 if name is not None else 0) | (16 if comment is not None else 0) | (2 if hcrc else 0)
     hdr = struct.pack("<BBBBIBB", 0x1F, 0x8B, 8, flg, 0, 0, 255)
     if extra is not None:
         hdr += struct.pack("<H", len(extra)) + extra
@@ -27,6 +27,8 @@ def _member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, name=None, extra=No
         hdr += name + b"\0"
     if comment is not None:
         hdr += comment + b"\0"
+    if hcrc:  # FHCRC: low 16 bits of the CRC-32 of the header ("bad": one off)
+        hdr += struct.pack("<H", ((zlib.crc32(hdr) & 0xFFFF) + (1 if hcrc == "bad" else 0)) & 0xFFFF)
     return hdr + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
 
 
@@ -59,6 +61,8 @@ def test_gunzip_matches_zlib():
         streams.append(_member(d, 6, zlib.Z_FIXED))
         want.append(d)
         streams.append(_member(d, 6, zlib.Z_HUFFMAN_ONLY, name=b"series.bin", extra=b"xy\x03\x00abc", comment=b"c"))
+        want.append(d)
+        streams.append(_member(d, 5, name=b"n", hcrc=True))
         want.append(d)
         streams.append(gzip.compress(d, 5))  # what java.util.zip.GZIPOutputStream-like writers produce
         want.append(d)
@@ -118,7 +122,8 @@ def test_gunzip_failures():
     cases = [(bytes(bad_crc), len(data), -5), (bytes(bad_len), len(data), -5), (bytes(bad_magic), len(data), -5),
              (good[:-9], len(data), -5), (good[:60], len(data), -5), (bad_type, 100, -5), (b"", 10, -5), (good, len(data) - 1, -2),
              (good, len(data), len(data)),
-             (good + good[:30], len(data), -5)]  # a second member that opens with a valid header and then ends: EOFException
+             (good + good[:30], len(data), -5), (_member(data, 5, hcrc="bad"), len(data), -5),
+             (good + _member(data, 5, hcrc="bad"), 2 * len(data), len(data))]  # a bad header behind a good member ends the stream quietly  # a second member that opens with a valid header and then ends: EOFException
     try:
         zlib.decompress(bytes(flipped), 31)
         flipped_ok = True

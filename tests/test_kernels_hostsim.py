@@ -32,3 +32,15 @@ def test_record_kernels_under_asan(sim_main):
 
 def test_rans_kernels_under_asan(sim_main):
     assert "rans: ok" in _run(sim_main, "rans", "quick")
+
+
+def test_gunzip_kernel_under_asan(sim_main):
+    """Valid and mutated gzip members, every stream and output slot a heap block of its exact size: zlib's verdict, and not a
+    byte read or written outside."""
+    assert "gunzip: ok" in _run(sim_main, "gunzip")
+
+
+def test_bam_decoder_under_asan(sim_main):
+    """Stripes of BAM records with damaged fields in a heap block of their exact size: flagged, nothing touched outside."""
+    assert "bam fuzz: ok" in _run(sim_main, "bam")
+
