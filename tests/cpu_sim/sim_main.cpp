@@ -238,6 +238,75 @@ static int run_bam_fuzz(cramgpu_ctx* c) {
     return bad != 0;
 }
 
+// ---- BAM records out: every output (stripe, offsets, status) a heap block of its exact size
+static int run_bam_encode(cramgpu_ctx* c) {
+    std::mt19937 rng(8);
+    int bad = 0;
+    for (int round = 0; round < 40; round++) {
+        const int n = 1 + (int)(rng() % 70);
+        std::vector<int32_t> ref_id(n), st(n), en(n), bf(n), mf(n), mr(n), ms(n), tl(n), rl(n), nc(n), qst(n);
+        std::vector<int64_t> boff(n + 1), coff(n + 1), noff(n + 1), toff(n + 1);
+        Bytes mapq(n);
+        int64_t nb = 0, ncg = 0, nn = 0, nt = 0, total = 0;
+        const bool with_names = round & 1, with_tags = round & 2;
+        for (int r = 0; r < n; r++) {
+            rl[r] = (int)(rng() % 5 == 0 ? rng() % 3 : rng() % 200);
+            nc[r] = (int)(rng() % 5);
+            ref_id[r] = (int)(rng() % 4) - 1, st[r] = (int)(rng() % 100000), en[r] = st[r] + rl[r], bf[r] = (int)(rng() % 4096);
+            mf[r] = (int)(rng() % 4), mr[r] = (int)(rng() % 4) - 1, ms[r] = (int)(rng() % 1000) - 3, tl[r] = (int)(rng() % 999) - 500;
+            mapq[r] = (uint8_t)rng(), qst[r] = (int)(rng() % 3 == 0);
+            boff[r] = nb, coff[r] = ncg, noff[r] = nn, toff[r] = nt;
+            nb += rl[r], ncg += nc[r];
+            const int ln = with_names ? 1 + (int)(rng() % 20) : 0, lt = with_tags ? (int)(rng() % 30) : 0;
+            nn += ln, nt += lt;
+            int digits = 1;
+            for (long long v = 990 + r; v >= 10; v /= 10) digits++;
+            total += 36 + (with_names ? ln : digits) + 1 + 4 * nc[r] + (rl[r] + 1) / 2 + rl[r] + lt;
+        }
+        boff[n] = nb, coff[n] = ncg, noff[n] = nn, toff[n] = nt;
+        // inputs of exact size too (the kernel reads 16 bases at a time where the arena allows)
+        uint8_t* bases = new uint8_t[nb ? nb : 1];
+        uint8_t* quals = new uint8_t[nb ? nb : 1];
+        for (int64_t i = 0; i < nb; i++) bases[i] = (uint8_t)"ACGTNacgtn=MRSVWYHKDB.@"[rng() % 23], quals[i] = (uint8_t)rng();
+        uint32_t* cig = new uint32_t[ncg ? ncg : 1];
+        for (int64_t i = 0; i < ncg; i++) cig[i] = (uint32_t)rng();
+        uint8_t* names = new uint8_t[nn ? nn : 1];
+        uint8_t* tags = new uint8_t[nt ? nt : 1];
+        for (int64_t i = 0; i < nn; i++) names[i] = (uint8_t)('a' + rng() % 26);
+        for (int64_t i = 0; i < nt; i++) tags[i] = (uint8_t)rng();
+        cramgpu_bam_cols b{};
+        b.ref_id = ref_id.data(), b.aln_start = st.data(), b.aln_end = en.data(), b.mapq = mapq.data(), b.bam_flags = bf.data();
+        b.mate_flags = mf.data(), b.mate_ref = mr.data(), b.mate_start = ms.data(), b.tlen = tl.data(), b.read_len = rl.data();
+        b.base_off = boff.data(), b.bases = bases, b.quals = quals, b.qual_status = qst.data();
+        b.n_cigar = nc.data(), b.cigar_off = coff.data(), b.cigar = cig;
+        if (with_names) b.names = names, b.name_off = noff.data();
+        b.name_base = 990;
+        if (with_tags) b.tags = tags, b.tag_off = toff.data();
+        uint8_t* out = new uint8_t[total];
+        int64_t* rec_off = new int64_t[n + 1];
+        int32_t* status = new int32_t[n];
+        if (cramgpu_bam_encode_dev(c, n, &b, out, total, rec_off, status, nullptr) != 0 || rec_off[n] != total) {
+            printf("bam encode: rc / size mismatch (%lld vs %lld)\n", (long long)rec_off[n], (long long)total);
+            bad++;
+        }
+        int64_t at = 0;  // the stripe walks: block sizes chain to the end
+        for (int r = 0; r < n && !bad; r++) {
+            int32_t bs;
+            memcpy(&bs, out + at, 4);
+            if (rec_off[r] != at || bs < 32) bad++;
+            at += 4 + bs;
+        }
+        if (!bad && at != total) bad++;
+        // one byte short: nothing may be written
+        if (total > 1 && cramgpu_bam_encode_dev(c, n, &b, out, total - 1, rec_off, status, nullptr) != 0) bad++;
+        for (int r = 0; r < n && total > 1; r++)
+            if (status[r] != CRAMGPU_E_INSUFFICIENT) bad++;
+        delete[] bases; delete[] quals; delete[] cig; delete[] names; delete[] tags; delete[] out; delete[] rec_off; delete[] status;
+    }
+    printf("bam encode: %s\n", bad ? "FAILED" : "ok");
+    return bad != 0;
+}
+
 int main(int argc, char** argv) {
     std::string what = argc > 1 ? argv[1] : "all";
     cramgpu_ctx* c = cramgpu_open(0);
@@ -292,6 +361,7 @@ int main(int argc, char** argv) {
     if (!bad && (what == "records" || what == "all")) bad |= run_records(c);
     if (!bad && (what == "gunzip" || what == "all")) bad |= run_gunzip(c);
     if (!bad && (what == "bam" || what == "all")) bad |= run_bam_fuzz(c);
+    if (!bad && (what == "bam" || what == "all")) bad |= run_bam_encode(c);
     cramgpu_close(c);
     return bad;
 }
