@@ -866,21 +866,24 @@ struct LogRegs {  // live across half batches only so that they need no initiali
     "v_cndmask_b32_e64 %[lg], %[l0], %[l1], %[k1]\n\t"            \
     "v_cndmask_b32_e64 %[lg], %[lg], %[l2], %[k2]\n\t"            \
     "v_cndmask_b32_e64 %[lg], %[lg], %[l3], %[k3]\n\t"
-template <bool GENERAL>
-__device__ __forceinline__ uint32_t rot_steps(uint32_t x, const uint4 P, uint32_t sm, LogRegs& G, uint32_t& lg) {
+// Both variants in ONE asm statement, the choice made by a scalar branch inside it: two statements under a C++ branch
+// leave the compiler free to keep the state and the log in different registers on the two paths, and it then moves five
+// registers at every join (20 cycles per 16 steps).  gs = the half batch's general flag, already in a scalar register.
+// Measured and dropped: folding the rotate into the step's last add (v_add_u32_dpp of q * cmpl_freq with a DPP-moved
+// r + bias, 7 dependent instructions instead of 8 but 9 issued instead of 8) makes ONE block faster (8.40 -> 8.24 ms
+// for 1.5 MB) and the full launch slower (QS blocks 13.6 -> 15.2 ms): with the other waves of the launch on
+// the same SIMD a step is bound by vector issue slots, not by the chain's latency.
+__device__ __forceinline__ uint32_t rot_steps_both(uint32_t x, const uint4 P, uint32_t sm, uint32_t gs, LogRegs& G, uint32_t& lg) {
     uint32_t t, r, m, p;
     const unsigned long long k1 = 0x2222222222222222ull, k2 = 0x4444444444444444ull, k3 = 0x8888888888888888ull;
-    if (GENERAL)
-        asm volatile(ROT16(ROT_STEP_G) ROT_SELECT
-                     : [x] "+v"(x), [l0] "+v"(G.l0), [l1] "+v"(G.l1), [l2] "+v"(G.l2), [l3] "+v"(G.l3), [t] "=&v"(t),
-                       [r] "=&v"(r), [m] "=&v"(m), [p] "=&v"(p), [lg] "=&v"(lg)
-                     : [a] "v"(P.x), [b] "v"(P.y), [c] "v"(P.z), [d] "v"(P.w), [sm] "v"(sm), [k1] "s"(k1), [k2] "s"(k2),
-                       [k3] "s"(k3));
-    else
-        asm volatile(ROT16(ROT_STEP) ROT_SELECT
-                     : [x] "+v"(x), [l0] "+v"(G.l0), [l1] "+v"(G.l1), [l2] "+v"(G.l2), [l3] "+v"(G.l3), [t] "=&v"(t),
-                       [r] "=&v"(r), [m] "=&v"(m), [lg] "=&v"(lg)
-                     : [a] "v"(P.x), [b] "v"(P.y), [c] "v"(P.z), [d] "v"(P.w), [k1] "s"(k1), [k2] "s"(k2), [k3] "s"(k3));
+    asm volatile("s_cmp_eq_u32 %[gs], 0\n\t"
+                 "s_cbranch_scc1 .LrotF_%=\n\t" ROT16(ROT_STEP_G) "s_branch .LrotD_%=\n"
+                 ".LrotF_%=:\n\t" ROT16(ROT_STEP) ".LrotD_%=:\n\t" ROT_SELECT
+                 : [x] "+v"(x), [l0] "+v"(G.l0), [l1] "+v"(G.l1), [l2] "+v"(G.l2), [l3] "+v"(G.l3), [t] "=&v"(t),
+                   [r] "=&v"(r), [m] "=&v"(m), [p] "=&v"(p), [lg] "=&v"(lg)
+                 : [a] "v"(P.x), [b] "v"(P.y), [c] "v"(P.z), [d] "v"(P.w), [sm] "v"(sm), [gs] "s"(gs), [k1] "s"(k1), [k2] "s"(k2),
+                   [k3] "s"(k3)
+                 : "scc");
     return x;
 }
 #endif
@@ -995,13 +998,28 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
                     fn[h] = L->p3.gflag[sb1][h];
                     Pn[h] = L->p3.stage[sb1][h][cslot];
                 }
+                // the general flags of the four half batches into scalar registers up front: a flag read right in front of its
+                // branch makes the branch wait for the vector-to-scalar hand-over every time
+                uint32_t gs[kHalves];
 #pragma unroll
                 for (int h = 0; h < kHalves; h++) {
-                    const bool general = UNIFORM(fc[h]) != 0;
+#ifdef HIP_SIM
+                    gs[h] = UNIFORM(fc[h]);
+#else
+                    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(gs[h]) : "v"(fc[h]));  // volatile: stays up here
+#endif
+                }
+#pragma unroll
+                for (int h = 0; h < kHalves; h++) {
+                    const bool general = gs[h] != 0;
                     if (prof && h == 0) busy2 += (unsigned long long)(clock64() - tb);
                     if (prof && general) ngen++;
                     uint32_t lg;
+#ifdef HIP_SIM
                     x = general ? rot_steps<true>(x, Pc[h], Pc[h].w >> 31, logs, lg) : rot_steps<false>(x, Pc[h], 0u, logs, lg);
+#else
+                    x = rot_steps_both(x, Pc[h], Pc[h].w >> 31, gs[h], logs, lg);
+#endif
                     L->p3.xs[buf][h][l] = lg;
                 }
                 if ((l & 15) == 15) L->p3.fin[l >> 4] = x;
