@@ -170,6 +170,8 @@ SYMBOLS = {
     "cramgpu_bam_index": (I64, [P, I64, P, I64]),
     "cramgpu_slice_md5_dev": (I32, [P, I32, P, P, P, P, P, P]),
     "cramgpu_gunzip_dev": (I32, [P, P, P, P, I32, P, P]),
+    "cramgpu_gzip_dev": (I32, [P, P, P, P, I32, P, I32, P]),
+    "cramgpu_gzip_bound": (I64, [I64]),
     "cramgpu_bgzf_index": (I64, [P, I64, P, P, I64]),
     "cramgpu_ref_upload": (I32, [P, I32, P, I64]),
     "cramgpu_ref_drop": (I32, [P, I32]),

@@ -1073,6 +1073,22 @@ int32_t cramgpu_gunzip_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, 
     return 0;
 }
 
+int32_t cramgpu_gzip_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks, int32_t n,
+                         int32_t* d_out_len, int32_t bgzf, void* stream) {
+    if (!c || n < 0 || (n > 0 && (!d_in || !d_out || !d_blocks || !d_out_len))) return fail(CRAMGPU_E_ARG, "gzip: bad argument");
+    // like gunzip: no scratch of the context, not ordered against the context's other calls
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(launch_gzip(d_in, d_out, d_blocks, n, d_out_len, bgzf, pick(c, stream)));
+    return 0;
+}
+
+int64_t cramgpu_gzip_bound(int64_t n) {
+    if (n < 0) return fail(CRAMGPU_E_ARG, "gzip_bound: negative length");
+    // worst case = stored blocks: 5 bytes per 32 KiB block (+ up to 4 of the writer's word granularity), 18 of header, 8 of trailer
+    return n + 5 * ((n + 32767) / 32768 + 1) + 18 + 8 + 8;
+}
+
 int64_t cramgpu_bgzf_index(const uint8_t* data, int64_t len, int64_t* off, int32_t* usize, int64_t cap) {
     if (!data || len < 0 || (cap > 0 && (!off || !usize))) return fail(CRAMGPU_E_ARG, "bgzf_index: bad argument");
     int64_t at = 0, n = 0;

@@ -1,0 +1,424 @@
+// Z — gzip members written on the device (the encode halves): the external blocks the
+// reference stores with method GZIP (htsjdk!io/ExternalCompression#gzip L30-39 = java.util.zip.GZIPOutputStream at the
+// default level, called from htsjdk!structure/Block for the 18 gzip series of a container) and the BGZF blocks behind
+// src/main/java/htsjdk/samtools/cram/paralell/CramToBam_OBA_Function.java:68-75 (htsjdk!util/BlockCompressedOutputStream).
+// The formats are public: RFC 1952 (member: header, DEFLATE data, CRC-32, ISIZE), RFC 1951 (DEFLATE), SAM specification
+// §4.1 (BGZF: FEXTRA subfield 'BC' = member size - 1).  DEFLATE leaves the choice of matches and codes to the writer, so
+// byte identity with zlib is NOT part of the contract: the contract is that every conforming
+// inflater (zlib, GZIPInputStream, kernel G) returns the input, and the size is reported beside zlib's.
+//
+// Shape on the machine: as in G, one serial bit stream per member and the parallelism across members — a lane per stream,
+// kLanes streams per wave.  Per DEFLATE block of at most 32 KiB of input (positions and counts then fit 16 bits): pass 1
+// parses greedily with a single-probe hash table over 3-byte prefixes (LDS, 4 KiB per lane; emptied per block, so every
+// match lies inside the block and inside the window) and counts literal / length / distance symbols; the lane then builds
+// the two length-limited Huffman codes (insertion sort of the used symbols, Moffat & Katajainen's in-place
+// minimum-redundancy lengths, the Kraft repair that zlib-compatible writers use for the 15- / 7-bit limits), run-length
+// codes the lengths (symbols 16 / 17 / 18) and writes the dynamic block header; pass 2 repeats the same parse — it is
+// deterministic — and emits the codes.  A block whose dynamic form would not beat the stored form is stored.
+#include "internal.h"
+
+namespace {
+
+struct __attribute__((packed)) W32u { uint32_t v; };
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return reinterpret_cast<const W32u*>(p)->v; }
+
+constexpr int kLanes = 8;
+constexpr int kHashBits = 11, kHash = 1 << kHashBits;
+constexpr int kBlock = 32768;
+constexpr int kNL = 286, kND = 30, kNC = 19, kAll = kNL + kND;
+
+struct DeflateLds {
+    uint16_t hash[kHash][kLanes];
+    uint16_t freq[kAll][kLanes];   // symbol counts of the block, then the (bit-reversed) codes
+    uint16_t work[kNL][kLanes];    // sorted counts / the in-place tree
+    uint16_t syms[kAll][kLanes];   // symbols in sorted order, then the run-length tokens (symbol | extra << 5)
+    uint8_t len[kAll][kLanes];     // code lengths: literal / length symbols, then distance symbols
+    uint16_t clfreq[kNC][kLanes];  // code-length code: counts, then codes
+    uint8_t cllen[kNC][kLanes];
+    uint16_t num[16][kLanes];      // codes per length / next code per length
+    uint32_t crc[256];
+};
+static_assert(sizeof(DeflateLds) <= 64 * 1024, "static LDS of a workgroup");
+
+struct Col16 {
+    uint16_t* p;
+    __device__ __forceinline__ uint16_t& operator[](int i) const { return p[i * kLanes]; }
+};
+struct Col8 {
+    uint8_t* p;
+    __device__ __forceinline__ uint8_t& operator[](int i) const { return p[i * kLanes]; }
+};
+
+struct BitW {
+    uint8_t* o;
+    int32_t pos, cap;  // pos keeps counting past cap (nothing is stored there): the caller sees the overflow at the end
+    unsigned long long acc;
+    int cnt;
+};
+__device__ __forceinline__ void put(BitW& w, uint32_t v, int k) {  // k <= 32, v < 2^k
+    w.acc |= (unsigned long long)v << w.cnt;
+    w.cnt += k;
+    if (w.cnt >= 32) {
+        if (w.pos + 4 <= w.cap) reinterpret_cast<W32u*>(w.o + w.pos)->v = (uint32_t)w.acc;
+        w.pos += 4;
+        w.acc >>= 32;
+        w.cnt -= 32;
+    }
+}
+__device__ __forceinline__ void flush_bytes(BitW& w) {  // to a byte boundary, everything out
+    w.cnt = (w.cnt + 7) & ~7;
+    while (w.cnt > 0) {
+        if (w.pos < w.cap) w.o[w.pos] = (uint8_t)w.acc;
+        w.pos++;
+        w.acc >>= 8;
+        w.cnt -= 8;
+    }
+}
+
+// Code lengths (<= max_len) of the symbols with a non-zero count; returns how many there are.
+__device__ int build_lengths(Col16 freq, int n, int max_len, Col8 len, Col16 A, Col16 S, Col16 num) {
+    int m = 0;
+    for (int s = 0; s < n; s++) {
+        len[s] = 0;
+        const uint16_t f = freq[s];
+        if (f != 0) {  // insertion sort, ascending count (equal counts stay in symbol order)
+            int j = m;
+            while (j > 0 && A[j - 1] > f) {
+                A[j] = A[j - 1];
+                S[j] = S[j - 1];
+                j--;
+            }
+            A[j] = f;
+            S[j] = (uint16_t)s;
+            m++;
+        }
+    }
+    if (m == 1) len[S[0]] = 1;
+    if (m >= 2) {
+        // Moffat & Katajainen, "In-place calculation of minimum-redundancy codes" (1995): A holds counts, then parent
+        // indices of the internal nodes, then depths
+        A[0] = (uint16_t)(A[0] + A[1]);
+        int root = 0, leaf = 2;
+        for (int next = 1; next < m - 1; next++) {
+            if (leaf >= m || A[root] < A[leaf]) {
+                A[next] = A[root];
+                A[root++] = (uint16_t)next;
+            } else {
+                A[next] = A[leaf++];
+            }
+            if (leaf >= m || (root < next && A[root] < A[leaf])) {
+                A[next] = (uint16_t)(A[next] + A[root]);
+                A[root++] = (uint16_t)next;
+            } else {
+                A[next] = (uint16_t)(A[next] + A[leaf++]);
+            }
+        }
+        A[m - 2] = 0;
+        for (int next = m - 3; next >= 0; next--) A[next] = (uint16_t)(A[A[next]] + 1);
+        int avbl = 1, used = 0, dpth = 0;
+        root = m - 2;
+        int next = m - 1;
+        while (avbl > 0) {
+            while (root >= 0 && (int)A[root] == dpth) {
+                used++;
+                root--;
+            }
+            while (avbl > used) {
+                A[next--] = (uint16_t)dpth;
+                avbl--;
+            }
+            avbl = 2 * used;
+            dpth++;
+            used = 0;
+        }
+        // the limit: depths beyond it are cut to it, then codes are lengthened one at a time until the Kraft sum is 1 again
+        for (int l = 0; l < 16; l++) num[l] = 0;
+        for (int i = 0; i < m; i++) {
+            const int d = (int)A[i] < max_len ? (int)A[i] : max_len;
+            num[d] = (uint16_t)(num[d] + 1);
+        }
+        uint32_t total = 0;
+        for (int l = max_len; l >= 1; l--) total += (uint32_t)num[l] << (max_len - l);
+        while (total > (1u << max_len)) {
+            num[max_len] = (uint16_t)(num[max_len] - 1);
+            bool moved = false;
+            for (int l = max_len - 1; l >= 1; l--) {
+                if (!moved && num[l] != 0) {
+                    num[l] = (uint16_t)(num[l] - 1);
+                    num[l + 1] = (uint16_t)(num[l + 1] + 2);
+                    moved = true;
+                }
+            }
+            total--;
+        }
+        int k = 0;  // sorted order: rarest first, so the longest codes go first
+        for (int l = max_len; l >= 1; l--)
+            for (int c = (int)num[l]; c > 0; c--) len[S[k++]] = (uint8_t)l;
+    }
+    return m;
+}
+
+// canonical codes of the lengths (RFC 1951 §3.2.2), bit-reversed for a writer that sends a code's first bit lowest
+__device__ void assign_codes(Col8 len, int n, Col16 code, Col16 num) {
+    for (int l = 0; l < 16; l++) num[l] = 0;
+    for (int s = 0; s < n; s++) num[len[s]] = (uint16_t)(num[len[s]] + 1);
+    int c = 0, prev = 0;
+    for (int l = 1; l < 16; l++) {  // num[l] becomes next_code[l]
+        c = (c + prev) << 1;
+        prev = (int)num[l];
+        num[l] = (uint16_t)c;
+    }
+    for (int s = 0; s < n; s++) {
+        const int l = len[s];
+        uint32_t v = 0;
+        if (l != 0) {
+            v = __brev((uint32_t)num[l]) >> (32 - l);
+            num[l] = (uint16_t)(num[l] + 1);
+        }
+        code[s] = (uint16_t)v;
+    }
+}
+
+struct Lane {
+    Col16 hash, freq, work, syms, clfreq, num;
+    Col8 len, cllen;
+};
+
+// One greedy parse of p[0, n).  EMIT == false: counts symbols, returns the number of extra bits; EMIT == true: writes.
+template <bool EMIT>
+__device__ uint32_t parse(const uint8_t* p, int32_t n, const Lane& L, BitW& w) {
+    for (int i = 0; i < kHash; i++) L.hash[i] = 0xFFFF;
+    uint32_t extra = 0;
+    int32_t i = 0;
+    while (i < n) {
+        int32_t mlen = 0, cand = 0;
+        if (i + 4 <= n) {
+            const uint32_t w4 = ld32(p + i);
+            const uint32_t h = ((w4 & 0xFFFFFFu) * 2654435761u) >> (32 - kHashBits);
+            cand = (int32_t)L.hash[h];
+            L.hash[h] = (uint16_t)i;
+            if (cand != 0xFFFF && ((ld32(p + cand) ^ w4) & 0xFFFFFFu) == 0) {
+                const int32_t maxl = n - i < 258 ? n - i : 258;
+                mlen = 3;
+                bool go = true;
+                while (go && mlen + 4 <= maxl) {
+                    const uint32_t x = ld32(p + i + mlen) ^ ld32(p + cand + mlen);
+                    if (x != 0) {
+                        mlen += (__ffs((int)x) - 1) >> 3;
+                        go = false;
+                    } else {
+                        mlen += 4;
+                    }
+                }
+                while (go && mlen < maxl) {
+                    if (p[i + mlen] == p[cand + mlen])
+                        mlen++;
+                    else
+                        go = false;
+                }
+            }
+        }
+        if (mlen == 0) {
+            const int s = p[i];
+            if (EMIT)
+                put(w, L.freq[s], L.len[s]);
+            else
+                L.freq[s] = (uint16_t)(L.freq[s] + 1);
+            i++;
+        } else {
+            // length 3..258 -> symbol 257..285 + extra bits, distance 1..32768 -> symbol 0..29 + extra bits (RFC 1951 §3.2.5)
+            const int lm = mlen - 3;
+            int ls = 257 + lm, leb = 0;
+            if (lm >= 8) {
+                const int k = 31 - __clz(lm);
+                leb = k - 2;
+                ls = 261 + 4 * leb + ((lm >> leb) & 3);
+            }
+            if (mlen == 258) ls = 285, leb = 0;
+            const int dm = i - cand - 1;
+            int ds = dm, deb = 0;
+            if (dm >= 4) {
+                const int k = 31 - __clz(dm);
+                deb = k - 1;
+                ds = 2 * k + ((dm >> deb) & 1);
+            }
+            if (EMIT) {
+                put(w, (uint32_t)L.freq[ls] | (uint32_t)(lm & ((1 << leb) - 1)) << L.len[ls], L.len[ls] + leb);
+                put(w, (uint32_t)L.freq[kNL + ds] | (uint32_t)(dm & ((1 << deb) - 1)) << L.len[kNL + ds], L.len[kNL + ds] + deb);
+            } else {
+                L.freq[ls] = (uint16_t)(L.freq[ls] + 1);
+                L.freq[kNL + ds] = (uint16_t)(L.freq[kNL + ds] + 1);
+                extra += (uint32_t)(leb + deb);
+            }
+            if (mlen <= 32)  // the positions a short match covers enter the table too (both passes: the parse must repeat)
+                for (int32_t j = i + 1; j < i + mlen && j + 4 <= n; j++) {
+                    const uint32_t hj = ((ld32(p + j) & 0xFFFFFFu) * 2654435761u) >> (32 - kHashBits);
+                    L.hash[hj] = (uint16_t)j;
+                }
+            i += mlen;
+        }
+    }
+    return extra;
+}
+
+// order in which the header carries the code-length code's own lengths (RFC 1951 §3.2.7):
+// 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 — the last sixteen as nibbles of one constant
+__device__ __forceinline__ int cl_order(int i) { return i < 3 ? 16 + i : (int)((0xF1E2D3C4B5A69780ull >> (4 * (i - 3))) & 15u); }
+
+// code lengths of the block as the sequence the header carries: literal / length symbols [0, hlit), then distances
+__device__ __forceinline__ int seq_len(const Lane& L, int hlit, int i) { return i < hlit ? L.len[i] : L.len[kNL + i - hlit]; }
+
+__device__ void deflate_block(const uint8_t* p, int32_t n, bool last, const Lane& L, BitW& w) {
+    for (int s = 0; s < kAll; s++) L.freq[s] = 0;
+    L.freq[256] = 1;  // end of block
+    const uint32_t extra = parse<false>(p, n, L, w);
+    build_lengths(L.freq, kNL, 15, L.len, L.work, L.syms, L.num);
+    const Col16 dfreq{&L.freq[kNL]};
+    const Col8 dlen{&L.len[kNL]};
+    build_lengths(dfreq, kND, 15, dlen, L.work, L.syms, L.num);
+    uint32_t body = extra;
+    for (int s = 0; s < kAll; s++) body += (uint32_t)L.freq[s] * L.len[s];
+    int hlit = kNL, hdist = kND;
+    while (hlit > 257 && L.len[hlit - 1] == 0) hlit--;
+    while (hdist > 1 && dlen[hdist - 1] == 0) hdist--;
+    // run-length tokens of the hlit + hdist lengths (RFC 1951 §3.2.7: one sequence across both alphabets)
+    const int total = hlit + hdist;
+    for (int s = 0; s < kNC; s++) L.clfreq[s] = 0;
+    int nt = 0;
+    uint32_t hdr = 0;
+    for (int i = 0; i < total;) {
+        const int v = seq_len(L, hlit, i);
+        int run = 1;
+        while (i + run < total && seq_len(L, hlit, i + run) == v) run++;
+        i += run;
+        if (v != 0) {
+            L.syms[nt++] = (uint16_t)v;
+            L.clfreq[v] = (uint16_t)(L.clfreq[v] + 1);
+            run--;
+        }
+        while (run > 0) {
+            int sym, ext = 0, take = 1;
+            if (v == 0 && run >= 11) {
+                take = run < 138 ? run : 138;
+                sym = 18, ext = take - 11, hdr += 7;
+            } else if (v == 0 && run >= 3) {
+                take = run;
+                sym = 17, ext = take - 3, hdr += 3;
+            } else if (v != 0 && run >= 3) {
+                take = run < 6 ? run : 6;
+                sym = 16, ext = take - 3, hdr += 2;
+            } else {
+                sym = v;
+            }
+            L.syms[nt++] = (uint16_t)(sym | ext << 5);
+            L.clfreq[sym] = (uint16_t)(L.clfreq[sym] + 1);
+            run -= take;
+        }
+    }
+    const int mcl = build_lengths(L.clfreq, kNC, 7, L.cllen, L.work, Col16{&L.work[kNC]}, L.num);
+    if (mcl == 1) {  // a code-length code of one symbol is incomplete, which inflaters refuse: a second one-bit code completes it
+        const int other = L.cllen[0] != 0 ? 1 : 0;
+        L.cllen[other] = 1;
+    }
+    for (int s = 0; s < kNC; s++) hdr += (uint32_t)L.clfreq[s] * L.cllen[s];
+    int hclen = kNC;
+    while (hclen > 4 && L.cllen[cl_order(hclen - 1)] == 0) hclen--;
+    hdr += 3 + 14 + 3 * (uint32_t)hclen;
+    const uint32_t stored_bits = 3 + 7 + 32 + 8 * (uint32_t)n;
+    if (hdr + body >= stored_bits) {
+        // stored block (RFC 1951 §3.2.4): header bits, pad to a byte, LEN, ~LEN, the bytes (n <= 32768 < 65536)
+        put(w, last ? 1u : 0u, 3);
+        flush_bytes(w);
+        put(w, (uint32_t)n | (~(uint32_t)n << 16), 32);
+        int32_t i = 0;
+        for (; i + 4 <= n; i += 4) put(w, ld32(p + i), 32);
+        for (; i < n; i++) put(w, p[i], 8);
+    } else {
+        assign_codes(L.len, kNL, L.freq, L.num);
+        assign_codes(dlen, kND, dfreq, L.num);
+        assign_codes(L.cllen, kNC, L.clfreq, L.num);
+        put(w, (last ? 1u : 0u) | 2u << 1, 3);
+        put(w, (uint32_t)(hlit - 257) | (uint32_t)(hdist - 1) << 5 | (uint32_t)(hclen - 4) << 10, 14);
+        for (int i = 0; i < hclen; i++)
+            put(w, L.cllen[cl_order(i)], 3);
+        for (int t = 0; t < nt; t++) {
+            const int tok = L.syms[t], sym = tok & 31, ext = tok >> 5;
+            put(w, L.clfreq[sym], L.cllen[sym]);
+            if (sym == 16) put(w, (uint32_t)ext, 2);
+            if (sym == 17) put(w, (uint32_t)ext, 3);
+            if (sym == 18) put(w, (uint32_t)ext, 7);
+        }
+        parse<true>(p, n, L, w);
+        put(w, L.freq[256], L.len[256]);
+    }
+}
+
+__global__ __launch_bounds__(kLanes) void gzip_kernel(const uint8_t* in, uint8_t* out, const cramgpu_block* desc, int32_t n,
+                                                      int32_t* out_len, int32_t bgzf) {
+    __shared__ DeflateLds lds;
+    for (int i = threadIdx.x; i < 256; i += kLanes) {  // CRC-32 (IEEE 802.3, reflected 0xEDB88320) byte table
+        uint32_t c = (uint32_t)i;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        lds.crc[i] = c;
+    }
+    __syncthreads();
+    const int32_t k = (int32_t)(blockIdx.x * kLanes + threadIdx.x);
+    if (k < n) {
+        const int t = (int)threadIdx.x;
+        const cramgpu_block D = desc[k];
+        const Lane L{Col16{&lds.hash[0][t]}, Col16{&lds.freq[0][t]}, Col16{&lds.work[0][t]}, Col16{&lds.syms[0][t]},
+                     Col16{&lds.clfreq[0][t]}, Col16{&lds.num[0][t]}, Col8{&lds.len[0][t]}, Col8{&lds.cllen[0][t]}};
+        const uint8_t* p = in + D.in_off;
+        const int32_t len = D.in_len;
+        BitW w{out + D.out_off, 0, D.out_cap, 0ull, 0};
+        // member header (RFC 1952 §2.3): no name, no time, OS unknown; BGZF adds the 6-byte extra field whose size
+        // slot is filled in at the end
+        put(w, 0x00088B1Fu | (bgzf ? 4u << 24 : 0u), 32);
+        put(w, 0u, 32);
+        put(w, 0xFF00u, 16);
+        if (bgzf) {
+            put(w, 6u | (uint32_t)'B' << 16 | (uint32_t)'C' << 24, 32);
+            put(w, 2u, 32);  // SLEN = 2, BSIZE = 0 for now
+        }
+        if (len == 0) {
+            put(w, 3u, 10);  // one empty block of the fixed code: BFINAL, BTYPE 01, end of block (7 zero bits)
+        } else {
+            for (int32_t at = 0; at < len; at += kBlock) {
+                const int32_t m = len - at < kBlock ? len - at : kBlock;
+                deflate_block(p + at, m, at + m >= len, L, w);
+            }
+        }
+        flush_bytes(w);
+        uint32_t c = 0xFFFFFFFFu;
+        int32_t i = 0;
+        for (; i + 4 <= len; i += 4) {
+            uint32_t v = ld32(p + i);
+#pragma unroll
+            for (int z = 0; z < 4; z++, v >>= 8) c = lds.crc[(c ^ v) & 255u] ^ (c >> 8);
+        }
+        for (; i < len; i++) c = lds.crc[(c ^ p[i]) & 255u] ^ (c >> 8);
+        put(w, c ^ 0xFFFFFFFFu, 32);
+        put(w, (uint32_t)len, 32);
+        flush_bytes(w);
+        int32_t rc = w.pos;
+        if (w.pos > w.cap) rc = CRAMGPU_E_OUT_TOO_SMALL;
+        if (bgzf && rc > 0) {
+            if (rc > 65536) {
+                rc = CRAMGPU_E_OUT_TOO_SMALL;  // a BGZF member holds at most 64 KiB: the caller cuts smaller blocks
+            } else {
+                w.o[16] = (uint8_t)(rc - 1);
+                w.o[17] = (uint8_t)((rc - 1) >> 8);
+            }
+        }
+        out_len[k] = rc;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_gzip(const uint8_t* in, uint8_t* out, const cramgpu_block* d_desc, int32_t n, int32_t* out_len, int32_t bgzf,
+                       hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gzip_kernel, dim3((unsigned)((n + kLanes - 1) / kLanes)), dim3(kLanes), 0, s, in, out, d_desc, n, out_len, bgzf);
+    return hipGetLastError();
+}

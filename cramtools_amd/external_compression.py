@@ -177,6 +177,46 @@ class Engine:
             res.append(out[desc[i].out_off:desc[i].out_off + int(lens[i])].tobytes())
         return res
 
+    def gzip_dev(self, d_in, d_out, d_blocks, n, d_out_len, bgzf=False, stream=None):
+        """ExternalCompression#gzip for n streams at once (cramgpu_gzip_dev): one gzip member per descriptor, BGZF
+        members (with the 'BC' size field) when bgzf is set."""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().cramgpu_gzip_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), d_blocks.data_ptr(), n,
+                                               d_out_len.data_ptr(), 1 if bgzf else 0, s))
+
+    @staticmethod
+    def gzip_bound(n):
+        return int(_lib.check(_lib.lib().cramgpu_gzip_bound(int(n))))
+
+    def gzip_many(self, datas, bgzf=False, device="cuda:0", caps=None):
+        """[bytes] -> [gzip member]; raises CramGpuError for the first stream that fails (a slot too small, a BGZF
+        member beyond 64 KiB)."""
+        import torch
+        n = len(datas)
+        if n == 0:
+            return []
+        desc = (_lib.Block * n)()
+        in_off = out_off = 0
+        for i, d in enumerate(datas):
+            cap = self.gzip_bound(len(d)) if caps is None else int(caps[i])
+            desc[i] = _lib.Block(in_off, out_off, len(d), cap, 0, 0)
+            in_off += len(d)
+            out_off += cap
+        d_in = torch.as_tensor(np.frombuffer(b"".join(bytes(d) for d in datas) + bytes(16), np.uint8).copy()).to(device)
+        d_out = torch.zeros(out_off + 16, dtype=torch.uint8, device=device)
+        d_desc = torch.as_tensor(np.frombuffer(bytes(desc), np.uint8).copy()).to(device)
+        d_len = torch.zeros(n, dtype=torch.int32, device=device)
+        self.gzip_dev(d_in, d_out, d_desc, n, d_len, bgzf)
+        lens = d_len.cpu().numpy()
+        out = d_out.cpu().numpy()
+        res = []
+        for i in range(n):
+            if lens[i] < 0:
+                raise CramGpuError(int(lens[i]), "gzip stream %d" % i)
+            res.append(out[desc[i].out_off:desc[i].out_off + int(lens[i])].tobytes())
+        return res
+
     def gather_dev(self, d_src, d_pos, d_len, n, max_len, d_dst, d_dst_off, align=16, stream=None):
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream

@@ -515,6 +515,23 @@ int64_t cramgpu_bam_index(const uint8_t* bam, int64_t len, int64_t* rec_off, int
 int32_t cramgpu_gunzip_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks,
                            int32_t n_blocks, int32_t* d_out_len, void* stream);
 
+/* The encode halves of the same two rows: htsjdk!io/ExternalCompression#gzip (L30-39, a java.util.zip.GZIPOutputStream)
+ * for the GZIP external blocks, and the BGZF members htsjdk!util/BlockCompressedOutputStream writes behind
+ * src/main/java/htsjdk/samtools/cram/paralell/CramToBam_OBA_Function.java:68-75.  Stream k = d_in[in_off, in_off + in_len)
+ * of d_blocks[k] (a DEVICE array) becomes ONE gzip member at d_out + out_off, at most out_cap bytes (cramgpu_gzip_bound
+ * always suffices); d_out_len[k] = its size or CRAMGPU_E_OUT_TOO_SMALL.  bgzf != 0: the member carries the 'BC' extra
+ * field with its own size (SAM specification 4.1) and must fit 64 KiB (else CRAMGPU_E_OUT_TOO_SMALL: cut the input into
+ * smaller blocks; 65280 bytes always fit).  DEFLATE leaves matches and codes to the writer, so the bytes differ from
+ * zlib's (SURVEY 8(f) row 2 puts byte identity outside the contract): the contract is that every conforming inflater —
+ * zlib, GZIPInputStream, cramgpu_gunzip_dev — returns the input.  Dynamic Huffman blocks of at most 32 KiB of input over
+ * a greedy single-probe LZ77 parse; a block that would not shrink is stored.  Stream-ordered, does not synchronise, uses
+ * no scratch of the context (not ordered against calls on other streams). */
+int32_t cramgpu_gzip_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks, int32_t n_blocks,
+                         int32_t* d_out_len, int32_t bgzf, void* stream);
+
+/* Host: an out_cap that cramgpu_gzip_dev never exceeds for n input bytes. */
+int64_t cramgpu_gzip_bound(int64_t n);
+
 /* Host: the BGZF blocks of a file image — off[cap] (off[n] = len when n < cap) and the uncompressed size of every block
  * (its ISIZE), from the 'BC' subfield of the headers; nothing is inflated.  Returns the number of blocks or
  * CRAMGPU_E_CORRUPT. */

@@ -146,6 +146,7 @@ inline unsigned __brev(unsigned v) {
     return __builtin_bswap32(v);
 }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
 inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <random>
 #include <string>
 #include <vector>
@@ -178,6 +179,98 @@ static int run_gunzip(cramgpu_ctx* c) {
         delete[] k.out;
     }
     printf("gunzip: %s (%d streams: %d valid, %d refused)\n", bad ? "FAILED" : "ok", n, ok, refused);
+    return bad != 0;
+}
+
+// ---- gzip written by the kernel, under the sanitizers: inputs and output slots are heap blocks of their exact sizes;
+// zlib's inflate and the gunzip kernel must both return the input; slots one byte short must be refused
+static int run_gzip(cramgpu_ctx* c) {
+    std::mt19937 rng(17);
+    std::vector<Bytes> plain;
+    for (int n : {0, 1, 2, 3, 4, 5, 9, 300, 5000, 32768, 32769, 40000, 70001}) {
+        Bytes a((size_t)n), b((size_t)n), r((size_t)n), t((size_t)n);
+        for (int i = 0; i < n; i++) {
+            a[i] = "ACGT"[rng() & 3], b[i] = (uint8_t)((i / 97) % 3 + 60), r[i] = (uint8_t)rng();
+            t[i] = (uint8_t)("the quick brown fox jumps over the lazy dog "[(i + (rng() % 50 == 0)) % 44]);
+        }
+        plain.push_back(a), plain.push_back(b), plain.push_back(r), plain.push_back(t);
+    }
+    {   // Fibonacci counts: an optimal code deeper than 15 bits, so the length limit has to act (literals, and the
+        // code-length code's 7 bits through the spread of lengths this produces)
+        Bytes f;
+        uint32_t x = 1, y = 1;
+        for (int sym = 0; sym < 21; sym++) {
+            for (uint32_t k = 0; k < x; k++) f.push_back((uint8_t)(33 + sym * 7));
+            const uint32_t z = x + y;
+            x = y, y = z;
+        }
+        std::shuffle(f.begin(), f.end(), rng);
+        plain.push_back(f);
+        Bytes zeros(66000, 0);
+        plain.push_back(zeros);
+    }
+    int bad = 0, total = 0;
+    size_t raw = 0, comp = 0, zl = 0;
+    for (int bgzf = 0; bgzf < 2; bgzf++) {
+        struct Case { Bytes* in; uint8_t* out; size_t cap; bool tight; };
+        std::vector<Case> cases;
+        for (const Bytes& d : plain) {
+            if (bgzf && d.size() > 65000) continue;
+            for (int tight = 0; tight < 2; tight++) {
+                Case k;
+                k.in = new Bytes(d);
+                k.in->shrink_to_fit();
+                k.cap = (size_t)cramgpu_gzip_bound((int64_t)d.size());
+                k.tight = tight != 0;
+                cases.push_back(k);
+            }
+        }
+        const int n = (int)cases.size();
+        // first pass with bound-sized slots gives the sizes; the tight cases then get a slot one byte short of theirs
+        std::vector<cramgpu_block> blocks(n);
+        std::vector<int32_t> lens(n, 12345);
+        for (int pass = 0; pass < 2; pass++) {
+            for (int i = 0; i < n; i++) {
+                if (pass == 1 && cases[i].tight) cases[i].cap = (size_t)lens[i] - 1;
+                if (pass == 1 && !cases[i].tight) cases[i].cap = (size_t)lens[i];
+                cases[i].out = new uint8_t[cases[i].cap ? cases[i].cap : 1];
+            }
+            const uint8_t* in0 = cases[n - 1].in->data();  // an empty vector has no storage: its offset is never used
+            uint8_t* out0 = cases[0].out;
+            for (int i = 0; i < n; i++)
+                blocks[i] = cramgpu_block{cases[i].in->empty() ? 0 : (int64_t)(cases[i].in->data() - in0), (int64_t)(cases[i].out - out0),
+                                          (int32_t)cases[i].in->size(), (int32_t)cases[i].cap, 0, 0};
+            std::vector<int32_t> got(n, 12345);
+            if (cramgpu_gzip_dev(c, in0, out0, blocks.data(), n, got.data(), bgzf, nullptr) != 0) { printf("gzip rc %s\n", cramgpu_last_error()); return 1; }
+            for (int i = 0; i < n; i++) {
+                const Case& k = cases[i];
+                total++;
+                if (pass == 1 && k.tight) {
+                    if (got[i] != CRAMGPU_E_OUT_TOO_SMALL) bad++, printf("gzip case %d: a slot one byte short gave %d\n", i, got[i]);
+                } else {
+                    Bytes s(k.out, k.out + (got[i] > 0 ? got[i] : 0)), back;
+                    const int r = got[i] > 0 ? gz_ref(s, k.in->size(), back) : -9;
+                    if (r != 0 || back != *k.in) bad++, printf("gzip case %d (n=%zu bgzf=%d): kernel %d, zlib verdict %d\n", i, k.in->size(), bgzf, got[i], r);
+                    if (pass == 1 && got[i] != lens[i]) bad++, printf("gzip case %d: size changed between runs (%d, %d)\n", i, lens[i], got[i]);
+                    if (bgzf && got[i] > 18 && (s[3] != 4 || s[12] != 'B' || s[13] != 'C' || (int)(s[16] | s[17] << 8) != got[i] - 1))
+                        bad++, printf("gzip case %d: BGZF header\n", i);
+                    if (pass == 0 && got[i] > 0) {
+                        // the gunzip kernel reads it back too
+                        Bytes o(k.in->size() + 1);
+                        cramgpu_block b1{0, 0, got[i], (int32_t)k.in->size(), 0, 0};
+                        int32_t l1 = 0;
+                        cramgpu_gunzip_dev(c, s.data(), o.data(), &b1, 1, &l1, nullptr);
+                        if (l1 != (int)k.in->size() || (!k.in->empty() && memcmp(o.data(), k.in->data(), k.in->size()))) bad++, printf("gzip case %d: gunzip kernel gave %d\n", i, l1);
+                        if (!bgzf && !k.tight) raw += k.in->size(), comp += (size_t)got[i], zl += gz_make(*k.in, 6, Z_DEFAULT_STRATEGY).size();
+                    }
+                }
+                if (pass == 0) lens[i] = got[i];
+            }
+            for (Case& k : cases) delete[] k.out;
+        }
+        for (Case& k : cases) delete k.in;
+    }
+    printf("gzip: %s (%d members; %zu raw bytes -> %zu, zlib level 6: %zu)\n", bad ? "FAILED" : "ok", total, raw, comp, zl);
     return bad != 0;
 }
 
@@ -360,6 +453,7 @@ int main(int argc, char** argv) {
     }
     if (!bad && (what == "records" || what == "all")) bad |= run_records(c);
     if (!bad && (what == "gunzip" || what == "all")) bad |= run_gunzip(c);
+    if (!bad && (what == "gzip" || what == "all")) bad |= run_gzip(c);
     if (!bad && (what == "bam" || what == "all")) bad |= run_bam_fuzz(c);
     if (!bad && (what == "bam" || what == "all")) bad |= run_bam_encode(c);
     cramgpu_close(c);

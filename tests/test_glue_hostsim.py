@@ -180,3 +180,12 @@ def test_gunzip_test_bodies(hostsim, monkeypatch):
     t.test_bgzf_blocks()
     t.test_gunzip_failures()
 
+
+def test_gzip_test_bodies(hostsim, monkeypatch):
+    """tests/test_gzip_gpu.py on the host build of csrc/deflate.hip."""
+    import test_gzip_gpu as t
+    monkeypatch.setattr(t, "DEV", "cpu")
+    t.test_members_inflate_to_the_input()
+    t.test_bgzf_image()
+    t.test_slot_too_small()
+

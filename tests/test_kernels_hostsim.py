@@ -40,6 +40,13 @@ def test_gunzip_kernel_under_asan(sim_main):
     assert "gunzip: ok" in _run(sim_main, "gunzip")
 
 
+def test_gzip_kernel_under_asan(sim_main):
+    """Members written by the gzip kernel from inputs and into slots of exact size (block boundaries, an alphabet whose
+    optimal code is deeper than 15 bits, incompressible and empty inputs, BGZF): zlib and the gunzip kernel return the input,
+    a slot one byte short is refused, and not a byte is read or written outside."""
+    assert "gzip: ok" in _run(sim_main, "gzip")
+
+
 def test_bam_decoder_under_asan(sim_main):
     """Stripes of BAM records with damaged fields in a heap block of their exact size: flagged, nothing touched outside."""
     out = _run(sim_main, "bam")
