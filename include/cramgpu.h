@@ -499,12 +499,12 @@ int32_t cramgpu_bam_decode_dev(cramgpu_ctx* ctx, int32_t n_reads, const uint8_t*
 int64_t cramgpu_bam_index(const uint8_t* bam, int64_t len, int64_t* rec_off, int64_t cap);
 
 /* =====================================================================================================
- * gunzip (the decode halves): htsjdk!io/ExternalCompression#gunzip (L41-48, a
+ * gunzip and gzip: htsjdk!io/ExternalCompression#gunzip (L41-48, a
  * java.util.zip.GZIPInputStream read to its end) as htsjdk!structure/Block#uncompress (L228-262) calls it for the GZIP
  * external blocks of a container, and the BGZF blocks of a BAM file (SAM specification §4.1; htsjdk!util/
  * BlockCompressedInputStream in front of Bam_OBA_Supplier).  RFC 1952 members (several in a row are read through, as
  * GZIPInputStream does; bytes behind the last member that are no header are ignored), RFC 1951 data, CRC-32 and ISIZE
- * checked.  Compression stays with the host (byte identity with zlib level 5 is outside the parity contract).
+ * checked.  The way back is cramgpu_gzip_dev below.
  * ===================================================================================================== */
 
 /* Stream k = d_in[in_off, in_off + in_len) of d_blocks[k] (a DEVICE array; offsets need no alignment, `order` is ignored)
