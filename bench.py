@@ -451,6 +451,42 @@ class DecodeStep:
         cont = reads.read_cont.to(torch.int64)
         self.q_off = qs_off[cont] + (reads.base_off - first[cont])
 
+    def gzip_series(self, reps=2):
+        """The encode half of the GZIP series (ExternalCompression#gzip; outside every timed region): the raw streams the
+        leg inflated are written as gzip members by the device (cramgpu_gzip_dev), inflated again by the gunzip kernel and
+        compared; sizes beside the zlib level 5 members made at set-up."""
+        if not getattr(self, "n_gz", 0):
+            return None
+        old = (_lib.Block * self.n_gz).from_buffer_copy(self.d_gz_desc.cpu().numpy().tobytes())
+        enc, back, at = (_lib.Block * self.n_gz)(), (_lib.Block * self.n_gz)(), 0
+        for i in range(self.n_gz):
+            cap = xc.Engine.gzip_bound(old[i].out_cap)
+            enc[i] = _lib.Block(old[i].out_off, at, old[i].out_cap, cap, 0, 0)
+            at += cap
+        d_enc = torch.as_tensor(np.frombuffer(bytes(enc), np.uint8).copy()).to(self.dev)
+        d_z = torch.zeros(at + 16, dtype=torch.uint8, device=self.dev)
+        d_zlen = torch.zeros(self.n_gz, dtype=torch.int32, device=self.dev)
+        ms = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.eng.gzip_dev(self.d_gz_raw, d_z, d_enc, self.n_gz, d_zlen)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        zl = d_zlen.cpu().numpy()
+        assert (zl > 0).all(), "a GZIP series failed to compress"
+        for i in range(self.n_gz):
+            back[i] = _lib.Block(enc[i].out_off, old[i].out_off, int(zl[i]), old[i].out_cap, 0, 0)
+        d_back = torch.zeros_like(self.d_gz_raw)
+        d_blen = torch.zeros(self.n_gz, dtype=torch.int32, device=self.dev)
+        self.eng.gunzip_dev(d_z, d_back, torch.as_tensor(np.frombuffer(bytes(back), np.uint8).copy()).to(self.dev), self.n_gz, d_blen)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_blen.cpu().numpy(), self.gz_raw_len) and torch.equal(d_back, self.d_gz_raw), "gzip -> gunzip round trip"
+        return dict(ms=float(min(ms)), streams=self.n_gz, raw_bytes=self.gz_bytes[1], gz_bytes=int(zl.sum()), zlib_level5_bytes=self.gz_bytes[0],
+                    note="ExternalCompression#gzip of the same series on the device (cramgpu_gzip_dev), outside every timed region; "
+                         "every member inflated again by the gunzip kernel and compared with the series")
+
     def verify(self):
         w, reads = self.w, self.w["reads"]
         n = w["d_in"].numel() - 16
@@ -810,6 +846,8 @@ def main(argv=None, backend_factory=GpuBackend):
                                            if getattr(dec, "n_gz", 0) else None),
                                    rans_decode_GBps=algo / k2_s / 1e9, rans_decode_frac_of_hbm=algo / k2_s / 1e9 / HBM_PEAK_GBS,
                                    parity=dec_parity)
+            if hasattr(dec, "gzip_series"):
+                extra["decode"]["gzip_writer"] = dec.gzip_series()
             if getattr(dec, "bam_ms", None):
                 bam_s = float(np.mean(dec.bam_ms)) / 1e3
                 extra["decode"]["assembly"] = dict(
