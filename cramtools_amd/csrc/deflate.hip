@@ -29,8 +29,8 @@ constexpr int kNL = 286, kND = 30, kNC = 19, kAll = kNL + kND;
 
 template <int LANES>
 struct DeflateLds {  // per-lane arrays interleaved by lane
-    uint16_t hash[kHash][LANES];
-    uint8_t tag[kHash][LANES];    // 8 more bits of the position's hash
+    uint16_t hash[kHash + 1][LANES];  // + a spare slot for the positions that have no 3 bytes (and one to compare) behind them
+    uint8_t tag[kHash + 1][LANES];    // 8 more bits of the position's hash
     uint16_t freq[kAll][LANES];   // symbol counts of the block, then the (bit-reversed) codes
     uint16_t work[kNL][LANES];    // sorted counts / the in-place tree
     uint16_t syms[kAll][LANES];   // symbols in sorted order, then the run-length tokens (symbol | extra << 5)
@@ -207,7 +207,7 @@ __device__ __forceinline__ unsigned long long ld64s(const uint8_t* p, int32_t q,
 // candidate's bytes are only fetched when they are almost surely a match.
 template <bool EMIT>
 __device__ uint32_t parse(const uint8_t* p, int32_t n, const Lane& L, BitW& w) {
-    for (int i = 0; i < kHash; i++) L.hash[i] = 0xFFFF;
+    for (int i = 0; i <= kHash; i++) L.hash[i] = 0xFFFF;
     uint32_t extra = 0;
     unsigned long long lo = ld64s(p, 0, n), hi = ld64s(p, 8, n), nx = ld64s(p, 16, n);
     int32_t skip = 0;
@@ -219,22 +219,28 @@ __device__ uint32_t parse(const uint8_t* p, int32_t n, const Lane& L, BitW& w) {
             nx = ld64s(p, i + 16, n);
         }
         const uint32_t w4 = (uint32_t)(o == 0 ? lo : (lo >> (8 * o)) | (hi << (64 - 8 * o)));
-        int32_t cand = 0;
-        bool hit = false;
-        if (i + 4 <= n) {
-            const uint32_t hh = (w4 & 0xFFFFFFu) * 2654435761u;
-            const uint32_t h = hh >> (32 - kHashBits);
-            const uint8_t tag = (uint8_t)(hh >> (24 - kHashBits));
-            cand = (int32_t)L.hash[h];
-            hit = cand != 0xFFFF && L.tag[h] == tag;
-            L.hash[h] = (uint16_t)i;
-            L.tag[h] = tag;
-        }
-        if (skip > 0) {
-            skip--;
-        } else {
-            int32_t mlen = 0;
-            if (hit && ((ld32(p + cand) ^ w4) & 0xFFFFFFu) == 0) {
+        // every LDS read the turn may need is issued here, before the first wait: table entry, tag, and the literal's
+        // count (pass 1) or code (pass 2) — one LDS latency per turn instead of three in a row.  The turn of a literal
+        // has no branch of its own (a divergent branch costs the wave ~40 cycles of mask bookkeeping, and the first
+        // version had a dozen per turn): the last three positions of a block use a spare table slot instead of a test,
+        // the count is written back with or without its increment, the code is put with a length of zero bits when
+        // there is none.  Only a table hit leaves the straight line.
+        const int lit = (int)(w4 & 255u);
+        const uint32_t hh = (w4 & 0xFFFFFFu) * 2654435761u;
+        const uint8_t tag = (uint8_t)(hh >> (24 - kHashBits));
+        const bool can = i + 4 <= n;
+        const uint32_t h = can ? hh >> (32 - kHashBits) : (uint32_t)kHash;
+        const uint16_t f_lit = L.freq[lit];
+        const uint8_t l_lit = EMIT ? L.len[lit] : (uint8_t)0;
+        const int32_t cand = (int32_t)L.hash[h];
+        const uint8_t tv = L.tag[h];
+        L.hash[h] = (uint16_t)i;
+        L.tag[h] = tag;
+        const bool active = skip == 0;
+        skip -= active ? 0 : 1;
+        int32_t mlen = 0;
+        if (active && can && cand != 0xFFFF && tv == tag) {
+            if (((ld32(p + cand) ^ w4) & 0xFFFFFFu) == 0) {
                 const int32_t maxl = n - i < 258 ? n - i : 258;
                 mlen = 3;
                 bool go = true;
@@ -253,14 +259,6 @@ __device__ uint32_t parse(const uint8_t* p, int32_t n, const Lane& L, BitW& w) {
                     else
                         go = false;
                 }
-            }
-            if (mlen == 0) {
-                const int s = (int)(w4 & 255u);
-                if (EMIT)
-                    put(w, L.freq[s], L.len[s]);
-                else
-                    L.freq[s] = (uint16_t)(L.freq[s] + 1);
-            } else {
                 // length 3..258 -> symbol 257..285 + extra bits, distance 1..32768 -> symbol 0..29 + extra bits (RFC 1951 §3.2.5)
                 const int lm = mlen - 3;
                 int ls = 257 + lm, leb = 0;
@@ -288,6 +286,11 @@ __device__ uint32_t parse(const uint8_t* p, int32_t n, const Lane& L, BitW& w) {
                 skip = mlen - 1;
             }
         }
+        const bool literal = active && mlen == 0;
+        if (EMIT)
+            put(w, literal ? (uint32_t)f_lit : 0u, literal ? (int)l_lit : 0);
+        else
+            L.freq[lit] = (uint16_t)(f_lit + (literal ? 1 : 0));
     }
     return extra;
 }
@@ -456,6 +459,7 @@ __global__ __launch_bounds__(LANES) void gzip_kernel(const uint8_t* in, uint8_t*
         flush_bytes(w);
         int32_t rc = w.pos;
         if (w.pos > w.cap) rc = CRAMGPU_E_OUT_TOO_SMALL;
+        if (len < 0 || D.out_cap < 0) rc = CRAMGPU_E_ARG;  // nothing was read or written: the loops above ran zero turns and cap < 0 admits no store
         if (bgzf && rc > 0) {
             if (rc > 65536) {
                 rc = CRAMGPU_E_OUT_TOO_SMALL;  // a BGZF member holds at most 64 KiB: the caller cuts smaller blocks

@@ -519,7 +519,7 @@ int32_t cramgpu_gunzip_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out
  * for the GZIP external blocks, and the BGZF members htsjdk!util/BlockCompressedOutputStream writes behind
  * src/main/java/htsjdk/samtools/cram/paralell/CramToBam_OBA_Function.java:68-75.  Stream k = d_in[in_off, in_off + in_len)
  * of d_blocks[k] (a DEVICE array) becomes ONE gzip member at d_out + out_off, at most out_cap bytes (cramgpu_gzip_bound
- * always suffices); d_out_len[k] = its size or CRAMGPU_E_OUT_TOO_SMALL.  bgzf != 0: the member carries the 'BC' extra
+ * always suffices); d_out_len[k] = its size, CRAMGPU_E_OUT_TOO_SMALL, or CRAMGPU_E_ARG for a negative in_len / out_cap.  bgzf != 0: the member carries the 'BC' extra
  * field with its own size (SAM specification 4.1) and must fit 64 KiB (else CRAMGPU_E_OUT_TOO_SMALL: cut the input into
  * smaller blocks; 65280 bytes always fit).  DEFLATE leaves matches and codes to the writer, so the bytes differ from
  * zlib's (SURVEY 8(f) row 2 puts byte identity outside the contract): the contract is that every conforming inflater —

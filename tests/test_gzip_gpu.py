@@ -107,5 +107,8 @@ def test_slot_too_small():
             with pytest.raises(_lib.CramGpuError) as e:
                 eng.gzip_many([d], device=DEV, caps=[cap])
             assert e.value.code == -2
+        with pytest.raises(_lib.CramGpuError) as e:
+            eng.gzip_many([d], device=DEV, caps=[-1])
+        assert e.value.code == -6
     finally:
         eng.close()
