@@ -187,5 +187,6 @@ def test_gzip_test_bodies(hostsim, monkeypatch):
     monkeypatch.setattr(t, "DEV", "cpu")
     t.test_members_inflate_to_the_input()
     t.test_bgzf_image()
+    t.test_long_series_as_several_members()
     t.test_slot_too_small()
 

@@ -95,6 +95,22 @@ def test_bgzf_image():
         eng.close()
 
 
+def test_long_series_as_several_members():
+    """A long series cut into pieces, one member each, written back to back: GZIPInputStream-style readers (Python's gzip,
+    the gunzip kernel) read the concatenation as ONE stream — the way to spread a long series over many lanes."""
+    from cramtools_amd import external_compression as xc
+    rng = np.random.default_rng(43)
+    series = _itf8ish(rng, 60000)
+    pieces = [series[i:i + 8192] for i in range(0, len(series), 8192)]
+    eng = xc.Engine(0)
+    try:
+        image = b"".join(eng.gzip_many(pieces, device=DEV))
+        assert gzip.decompress(image) == series
+        assert eng.gunzip_many([image], [len(series)], device=DEV) == [series]
+    finally:
+        eng.close()
+
+
 def test_slot_too_small():
     from cramtools_amd import _lib, external_compression as xc
     rng = np.random.default_rng(41)
