@@ -546,6 +546,50 @@ class DecodeStep:
                 "the reads" % size)
 
 
+BLOCK_DTYPE = np.dtype([("in_off", "<i8"), ("out_off", "<i8"), ("in_len", "<i4"), ("out_cap", "<i4"), ("order", "<i4"), ("pad", "<i4")])
+
+
+def bgzf_image(dec):
+    """SURVEY 8(f) row 3, the last step of the way out: the BAM stripe cut into 65280-byte pieces (htsjdk's
+    BlockCompressedOutputStream block size) and written as BGZF members on the device (cramgpu_gzip_dev); every member is
+    inflated again by the gunzip kernel and compared with the stripe, a sample by zlib on the host.  Outside every timed
+    region of the headline."""
+    import zlib
+    assert C.sizeof(_lib.Block) == BLOCK_DTYPE.itemsize
+    size, piece, slot = dec.bam_bytes, 65280, 65536
+    n = (size + piece - 1) // piece
+    d = np.zeros(n, BLOCK_DTYPE)
+    d["in_off"] = np.arange(n, dtype=np.int64) * piece
+    d["out_off"] = np.arange(n, dtype=np.int64) * slot
+    d["in_len"] = np.minimum(piece, size - d["in_off"])
+    d["out_cap"] = slot
+    d_desc = torch.as_tensor(d.view(np.uint8)).to(dec.dev)
+    d_img = torch.zeros(n * slot + 16, dtype=torch.uint8, device=dec.dev)
+    d_len = torch.zeros(n, dtype=torch.int32, device=dec.dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    dec.eng.gzip_dev(dec.bam, d_img, d_desc, n, d_len, bgzf=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    lens = d_len.cpu().numpy()
+    assert (lens > 0).all(), "a BGZF member failed: %r" % (lens[lens <= 0][:4],)
+    b = np.zeros(n, BLOCK_DTYPE)
+    b["in_off"], b["out_off"], b["in_len"], b["out_cap"] = d["out_off"], d["in_off"], lens, d["in_len"]
+    d_back = torch.zeros(size + 16, dtype=torch.uint8, device=dec.dev)
+    d_blen = torch.zeros(n, dtype=torch.int32, device=dec.dev)
+    dec.eng.gunzip_dev(d_img, d_back, torch.as_tensor(b.view(np.uint8)).to(dec.dev), n, d_blen)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_blen.cpu().numpy(), d["in_len"]) and torch.equal(d_back[:size], dec.bam[:size]), "BGZF image -> stripe"
+    for k in (0, 1, n // 2, n - 1):
+        m = d_img[int(d["out_off"][k]):int(d["out_off"][k]) + int(lens[k])].cpu().numpy().tobytes()
+        raw = dec.bam[int(d["in_off"][k]):int(d["in_off"][k]) + int(d["in_len"][k])].cpu().numpy().tobytes()
+        assert m[12:14] == b"BC" and int.from_bytes(m[16:18], "little") == len(m) - 1 and zlib.decompress(m, 31) == raw, "BGZF member %d" % k
+    return dict(ms=ms, blocks=int(n), bam_bytes=int(size), bgzf_bytes=int(lens.sum()), GBps_in=size / ms / 1e6,
+                note="the stripe as BGZF members of 65280 input bytes (cramgpu_gzip_dev, bgzf); all members inflated again by the "
+                     "gunzip kernel and compared with the stripe, four of them by zlib")
+
+
 def host_threads():
     """Threads of the CPU legs: every core this process may use.  The GPU boxes show the whole machine in os.cpu_count()
     but give a job a share of it, exported as OMP_NUM_THREADS (16 per GPU); elsewhere it is os.cpu_count()."""
@@ -774,6 +818,7 @@ def main(argv=None, backend_factory=GpuBackend):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--no-bgzf", action="store_true", help="skip the BGZF image of the BAM stripe (2.7 GB through the gzip kernel)")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -856,6 +901,8 @@ def main(argv=None, backend_factory=GpuBackend):
                     ms=bam_s * 1e3, bam_bytes=dec.bam_bytes, GBps_written=dec.bam_bytes / bam_s / 1e9,
                     reads_per_s=a.reads / bam_s,
                     bam_decode_ms=getattr(dec, "bam_decode_ms", None))  # the stripe back into columns (BAMRecordCodec#decode)
+                if not a.no_bgzf and hasattr(dec, "bam_bytes"):
+                    extra["decode"]["assembly"]["bgzf"] = bgzf_image(dec)
         if not a.no_pcie and world == 1:
             extra["pcie_inclusive"] = be.pcie(w)
         total_raw = w["raw_bytes"] * world
