@@ -35,6 +35,9 @@ from cramtools_amd import _lib, sharding, synth_torch
 from cramtools_amd import external_compression as xc
 from cramtools_amd import records as rec
 
+# cramgpu_block as a numpy record (descriptor tables built without a Python loop)
+BLOCK_DTYPE = np.dtype([("in_off", "<i8"), ("out_off", "<i8"), ("in_len", "<i4"), ("out_cap", "<i4"), ("order", "<i4"), ("pad", "<i4")])
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 READS_PER_CONTAINER = 10000  # CramContext.java:33
 # series of the block corpus: (name, rANS order) — CompressionHeaderFactory#build L82-124
@@ -451,41 +454,51 @@ class DecodeStep:
         cont = reads.read_cont.to(torch.int64)
         self.q_off = qs_off[cont] + (reads.base_off - first[cont])
 
-    def gzip_series(self, reps=2):
+    def gzip_series(self, reps=2, piece=0):
         """The encode half of the GZIP series (ExternalCompression#gzip; outside every timed region): the raw streams the
         leg inflated are written as gzip members by the device (cramgpu_gzip_dev), inflated again by the gunzip kernel and
-        compared; sizes beside the zlib level 5 members made at set-up."""
+        compared; sizes beside the zlib level 5 members made at set-up.  piece > 0: series longer than that are cut into
+        pieces of that many bytes, one member each (GZIPInputStream reads members written back to back as one stream):
+        a call lasts as long as its longest stream."""
         if not getattr(self, "n_gz", 0):
             return None
-        old = (_lib.Block * self.n_gz).from_buffer_copy(self.d_gz_desc.cpu().numpy().tobytes())
-        enc, back, at = (_lib.Block * self.n_gz)(), (_lib.Block * self.n_gz)(), 0
-        for i in range(self.n_gz):
-            cap = xc.Engine.gzip_bound(old[i].out_cap)
-            enc[i] = _lib.Block(old[i].out_off, at, old[i].out_cap, cap, 0, 0)
-            at += cap
-        d_enc = torch.as_tensor(np.frombuffer(bytes(enc), np.uint8).copy()).to(self.dev)
+        old = np.frombuffer(self.d_gz_desc.cpu().numpy().tobytes(), BLOCK_DTYPE)
+        step = piece if piece > 0 else 1 << 30
+        src, ln = [], []
+        for o, n_raw in zip(old["out_off"].tolist(), old["out_cap"].tolist()):
+            for at in range(0, n_raw, step):
+                src.append(o + at)
+                ln.append(min(step, n_raw - at))
+        n = len(src)
+        enc = np.zeros(n, BLOCK_DTYPE)
+        enc["in_off"], enc["in_len"] = src, ln
+        enc["out_cap"] = [xc.Engine.gzip_bound(x) for x in ln]
+        enc["out_off"] = np.concatenate([[0], np.cumsum(enc["out_cap"].astype(np.int64))[:-1]])
+        at = int(enc["out_cap"].astype(np.int64).sum())
+        order = np.argsort(-enc["in_len"], kind="stable")  # longest first
+        enc = enc[order]
+        d_enc = torch.as_tensor(enc.view(np.uint8).copy()).to(self.dev)
         d_z = torch.zeros(at + 16, dtype=torch.uint8, device=self.dev)
-        d_zlen = torch.zeros(self.n_gz, dtype=torch.int32, device=self.dev)
+        d_zlen = torch.zeros(n, dtype=torch.int32, device=self.dev)
         ms = []
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.eng.gzip_dev(self.d_gz_raw, d_z, d_enc, self.n_gz, d_zlen)
+            self.eng.gzip_dev(self.d_gz_raw, d_z, d_enc, n, d_zlen)
             e1.record()
             torch.cuda.synchronize()
             ms.append(e0.elapsed_time(e1))
         zl = d_zlen.cpu().numpy()
         assert (zl > 0).all(), "a GZIP series failed to compress"
-        for i in range(self.n_gz):
-            back[i] = _lib.Block(enc[i].out_off, old[i].out_off, int(zl[i]), old[i].out_cap, 0, 0)
+        back = np.zeros(n, BLOCK_DTYPE)
+        back["in_off"], back["out_off"], back["in_len"], back["out_cap"] = enc["out_off"], enc["in_off"], zl, enc["in_len"]
         d_back = torch.zeros_like(self.d_gz_raw)
-        d_blen = torch.zeros(self.n_gz, dtype=torch.int32, device=self.dev)
-        self.eng.gunzip_dev(d_z, d_back, torch.as_tensor(np.frombuffer(bytes(back), np.uint8).copy()).to(self.dev), self.n_gz, d_blen)
+        d_blen = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        self.eng.gunzip_dev(d_z, d_back, torch.as_tensor(back.view(np.uint8).copy()).to(self.dev), n, d_blen)
         torch.cuda.synchronize()
-        assert np.array_equal(d_blen.cpu().numpy(), self.gz_raw_len) and torch.equal(d_back, self.d_gz_raw), "gzip -> gunzip round trip"
-        return dict(ms=float(min(ms)), streams=self.n_gz, raw_bytes=self.gz_bytes[1], gz_bytes=int(zl.sum()), zlib_level5_bytes=self.gz_bytes[0],
-                    note="ExternalCompression#gzip of the same series on the device (cramgpu_gzip_dev), outside every timed region; "
-                         "every member inflated again by the gunzip kernel and compared with the series")
+        assert np.array_equal(d_blen.cpu().numpy(), enc["in_len"]) and torch.equal(d_back, self.d_gz_raw), "gzip -> gunzip round trip"
+        return dict(ms=float(min(ms)), streams=self.n_gz, members=n, raw_bytes=self.gz_bytes[1], gz_bytes=int(zl.sum()),
+                    zlib_level5_bytes=self.gz_bytes[0])
 
     def verify(self):
         w, reads = self.w, self.w["reads"]
@@ -544,9 +557,6 @@ class DecodeStep:
         self.bam_bytes = size
         return ("; the %d-byte BAM stripe built from them (CIGARs from features, mate restoration, BAM records) decodes back to "
                 "the reads" % size)
-
-
-BLOCK_DTYPE = np.dtype([("in_off", "<i8"), ("out_off", "<i8"), ("in_len", "<i4"), ("out_cap", "<i4"), ("order", "<i4"), ("pad", "<i4")])
 
 
 def bgzf_image(dec):
@@ -892,7 +902,14 @@ def main(argv=None, backend_factory=GpuBackend):
                                    rans_decode_GBps=algo / k2_s / 1e9, rans_decode_frac_of_hbm=algo / k2_s / 1e9 / HBM_PEAK_GBS,
                                    parity=dec_parity)
             if hasattr(dec, "gzip_series"):
-                extra["decode"]["gzip_writer"] = dec.gzip_series()
+                gw = dec.gzip_series()
+                if gw is not None:
+                    cut = dec.gzip_series(piece=8192)
+                    gw.update(ms_cut_8k=cut["ms"], members_cut_8k=cut["members"], gz_bytes_cut_8k=cut["gz_bytes"],
+                              note="ExternalCompression#gzip of the same series on the device (cramgpu_gzip_dev), outside every timed "
+                                   "region; every member inflated again by the gunzip kernel and compared with the series; "
+                                   "*_cut_8k: series longer than 8 KiB written as several members back to back")
+                extra["decode"]["gzip_writer"] = gw
             if getattr(dec, "bam_ms", None):
                 bam_s = float(np.mean(dec.bam_ms)) / 1e3
                 extra["decode"]["assembly"] = dict(
