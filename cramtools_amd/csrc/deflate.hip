@@ -11,7 +11,7 @@
 // 2 to 8 streams per wave.  Per DEFLATE block of at most 32 KiB of input (positions and counts then fit 16 bits): pass 1
 // parses greedily with a single-probe hash table over 3-byte prefixes (LDS, 1.5 KiB per lane; emptied per block, so every
 // match lies inside the block and inside the window) and counts literal / length / distance symbols; the lane then builds
-// the two length-limited Huffman codes (insertion sort of the used symbols, Moffat & Katajainen's in-place
+// the two length-limited Huffman codes (counting sort of the used symbols, Moffat & Katajainen's in-place
 // minimum-redundancy lengths, the Kraft repair that zlib-compatible writers use for the 15- / 7-bit limits), run-length
 // codes the lengths (symbols 16 / 17 / 18) and writes the dynamic block header; pass 2 repeats the same parse — it is
 // deterministic — and emits the codes.  A block whose dynamic form would not beat the stored form is stored.
@@ -43,6 +43,7 @@ struct DeflateLds {  // per-lane arrays interleaved by lane
     uint32_t crc[256];
 };
 static_assert(sizeof(DeflateLds<kMaxLanes>) <= 80 * 1024, "two workgroups per CU");
+static_assert(kHash >= 256, "the match table doubles as the 256 counters of the counting sort");
 
 struct Col16 {
     uint16_t* p;
@@ -81,22 +82,56 @@ __device__ __forceinline__ void flush_bytes(BitW& w) {  // to a byte boundary, e
     }
 }
 
-// Code lengths (<= max_len) of the symbols with a non-zero count; returns how many there are.
-__device__ int build_lengths(Col16 freq, int n, int max_len, Col8 len, Col16 A, Col16 S, Col16 num) {
+// Code lengths (<= max_len) of the symbols with a non-zero count; returns how many there are.  cnt: 256 cells of scratch
+// for the counting sort of large alphabets (none: insertion sort only).
+__device__ int build_lengths(Col16 freq, int n, int max_len, Col8 len, Col16 A, Col16 S, Col16 num, Col16 cnt) {
     int m = 0;
-    for (int s = 0; s < n; s++) {
+    for (int s = 0; s < n; s++) {  // the used symbols, in symbol order, parked in A
         len[s] = 0;
-        const uint16_t f = freq[s];
-        if (f != 0) {  // insertion sort, ascending count (equal counts stay in symbol order)
-            int j = m;
+        if (freq[s] != 0) A[m++] = (uint16_t)s;
+    }
+    // (A, S) = (count, symbol) ascending by count, equal counts in symbol order
+    if (cnt.p != nullptr && m > 48) {
+        // two stable counting passes over the count's bytes: ~4 m + 512 LDS round trips instead of the ~m * m / 4 of the
+        // insertion sort (a block of BAM-like bytes uses ~280 symbols)
+        for (int pass = 0; pass < 2; pass++) {
+            const Col16 src = pass == 0 ? A : S, dst = pass == 0 ? S : A;
+            const int sh = 8 * pass;
+            for (int i = 0; i < 256; i++) cnt[i] = 0;
+            for (int i = 0; i < m; i++) {
+                const int b = (freq[src[i]] >> sh) & 255;
+                cnt[b] = (uint16_t)(cnt[b] + 1);
+            }
+            int run = 0;
+            for (int i = 0; i < 256; i++) {
+                const int c = cnt[i];
+                cnt[i] = (uint16_t)run;
+                run += c;
+            }
+            for (int i = 0; i < m; i++) {
+                const uint16_t sym = src[i];
+                const int b = (freq[sym] >> sh) & 255;
+                const int at = cnt[b];
+                cnt[b] = (uint16_t)(at + 1);
+                dst[at] = sym;
+            }
+        }
+        for (int i = 0; i < m; i++) {
+            const uint16_t sym = A[i];
+            S[i] = sym;
+            A[i] = freq[sym];
+        }
+    } else {
+        for (int k = 0; k < m; k++) {  // insertion sort in place: slot k is read before anything is shifted into it
+            const uint16_t sym = A[k], f = freq[sym];
+            int j = k;
             while (j > 0 && A[j - 1] > f) {
                 A[j] = A[j - 1];
                 S[j] = S[j - 1];
                 j--;
             }
             A[j] = f;
-            S[j] = (uint16_t)s;
-            m++;
+            S[j] = sym;
         }
     }
     if (m == 1) len[S[0]] = 1;
@@ -339,10 +374,10 @@ __device__ void deflate_block(const uint8_t* p, int32_t n, bool last, const Lane
     L.freq[256] = 1;  // end of block
     const uint32_t extra = parse<false>(p, n, L, w, prof);
     GZ_STAMP(0);
-    build_lengths(L.freq, kNL, 15, L.len, L.work, L.syms, L.num);
+    build_lengths(L.freq, kNL, 15, L.len, L.work, L.syms, L.num, L.hash);
     const Col16 dfreq{&L.freq[kNL], L.freq.st};
     const Col8 dlen{&L.len[kNL], L.len.st};
-    build_lengths(dfreq, kND, 15, dlen, L.work, L.syms, L.num);
+    build_lengths(dfreq, kND, 15, dlen, L.work, L.syms, L.num, Col16{nullptr, 0});
     uint32_t body = extra;
     for (int s = 0; s < kAll; s++) body += (uint32_t)L.freq[s] * L.len[s];
     int hlit = kNL, hdist = kND;
@@ -382,7 +417,7 @@ __device__ void deflate_block(const uint8_t* p, int32_t n, bool last, const Lane
             run -= take;
         }
     }
-    const int mcl = build_lengths(L.clfreq, kNC, 7, L.cllen, L.work, Col16{&L.work[kNC], L.work.st}, L.num);
+    const int mcl = build_lengths(L.clfreq, kNC, 7, L.cllen, L.work, Col16{&L.work[kNC], L.work.st}, L.num, Col16{nullptr, 0});
     if (mcl == 1) {  // a code-length code of one symbol is incomplete, which inflaters refuse: a second one-bit code completes it
         const int other = L.cllen[0] != 0 ? 1 : 0;
         L.cllen[other] = 1;
