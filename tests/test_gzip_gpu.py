@@ -87,6 +87,10 @@ def test_bgzf_image():
         assert _lib.check(L.cramgpu_bgzf_index(img.ctypes.data, img.size, off.ctypes.data, usize.ctypes.data, n + 1)) == n
         assert usize.tolist() == [len(c) for c in chunks] and off[-1] == img.size
         assert b"".join(eng.gunzip_many([image[off[i]:off[i + 1]] for i in range(n)], usize, device=DEV)) == payload
+        # 65280 incompressible bytes (htsjdk's block size) still fit a member: stored blocks cost 5 bytes per 32 KiB
+        noise = rng.integers(0, 256, 65280).astype(np.uint8).tobytes()
+        m = eng.gzip_many([noise], bgzf=True, device=DEV)[0]
+        assert len(m) <= 65280 + 18 + 8 + 2 * 5 and gzip.decompress(m) == noise
         # 65536 random bytes cannot fit a 64 KiB member
         with pytest.raises(_lib.CramGpuError) as e:
             eng.gzip_many([rng.integers(0, 256, 65536).astype(np.uint8).tobytes()], bgzf=True, device=DEV)
