@@ -39,13 +39,11 @@
 
 namespace {
 
-constexpr int kSteps = 16;   // steps per half batch: 16 steps x 4 states = the 64 lanes of the helper wave
-constexpr int kHalves = 4;   // 16-step groups between two barriers (amortises the barrier and both waves' fixed costs)
-constexpr int kBatch = kSteps * kHalves;
-
-// records of a state are kStageRow apart: with 17 the helper's 16-byte stores (lanes = step-major) spread over the
-// banks (2-way instead of 4-way conflicts) and the chain wave's row-major reads stay conflict-free
-constexpr int kStageRow = 17;
+constexpr int kRun = 4;      // consecutive steps a chain lane codes on its own four records
+constexpr int kGroup = 16;   // steps per group: four runs, one per DPP bank of a row
+constexpr int kGroups = 4;   // groups between two barriers (amortises the barrier and both waves' fixed costs)
+constexpr int kBatch = kGroup * kGroups;
+constexpr int kStageBufs = 4;  // batch i-1 is being turned into bytes, i runs, i+1 is prefetched, i+2 is being staged
 
 constexpr int kWgThreads = 128;   // chain wave + helper wave
 
@@ -58,10 +56,12 @@ struct EncP2 {              // phase 2 (tables)
     uint32_t rowhdr[256];   // context-level header of each row: count | byte0 << 8 | byte1 << 16
 };
 struct alignas(16) EncP3 {  // phase 3 (coding loop)
-    uint4 stage[3][kHalves][kStageRow * 4];  // [buffer][half][state*kStageRow + step]: x_max-1, rcp_freq, bias, cmpl_freq | shift<<24 | small<<31
-    uint32_t xs[2][kHalves][64];  // [buffer][half][state*16 + step]: state before each step of the batch
+    // [buffer][helper lane * 4 + k]: the record of step 4 * (lane >> 2) + k of the batch, state 3 - (lane & 3):
+    // x_max-1, rcp_freq, bias, cmpl_freq | shift<<24 | small<<31.  A chain lane reads the four records of its run as 64 contiguous bytes.
+    uint4 stage[kStageBufs][kBatch * 4];
+    uint32_t xs[2][64];        // [buffer][helper lane]: state before the first step of that lane's run
     uint8_t ring[kRingBytes];  // input bytes (dense symbol indices when the order-1 tables are in LDS)
-    uint32_t gflag[3][kHalves];  // [buffer][half] != 0: the half batch holds a symbol with freq < 16
+    uint32_t gflag[kStageBufs];  // bit G: group G of the batch holds a symbol with freq < 16
     uint32_t fin[4];        // states after the last batch the chain ran
     unsigned long long cbusy, cbusy2, cgen;  // profiling runs only: cycles the chain wave spent outside barriers
 };
@@ -222,7 +222,7 @@ __device__ __forceinline__ void for_each_unit(const uint8_t* src, int32_t n16, i
 // words apart: at 256 every replica would put a symbol in the same LDS bank and the lanes that see the same symbol
 // (most of them, in a quality stream) would serialise exactly as without replicas.
 constexpr int kRep0 = 16, kRep0Stride = 257;
-static_assert(1024 + 2048 + kRep0 * kRep0Stride * 4 <= kTabBytes, "order-0 replicas must fit the table region");
+static_assert(1024 + 2048 <= kTabBytes && kRep0 * kRep0Stride * 4 <= kBigBytes, "order-0 counts, symbols and replicas must fit");
 __device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* rep) {
     const int l = (int)threadIdx.x;  // both waves
     constexpr int R = kRep0;
@@ -757,18 +757,19 @@ __device__ __forceinline__ void chunk_store(const ChunkRegs& R, uint8_t* ring, c
     }
 }
 
-// Helper lane l owns step (l >> 2) and state 3 - (l & 3) of a batch, so that lane order is the reference's emission
-// order.  Its input position falls by a constant from batch to batch, and its pair is active for a contiguous range of
-// steps, so the per-batch bookkeeping is a handful of adds and compares.
+// Helper lane l owns the run g = l >> 2 (steps 4g .. 4g+3 of the batch) of state 3 - (l & 3): lane order is then the
+// reference's emission order (state 3,2,1,0 per step) within a step, runs in lane order, and the four steps of a run are
+// consecutive input positions of one state.  The lane's input position falls by a constant from batch to batch and its
+// steps are active for a contiguous range, so the per-batch bookkeeping is a handful of adds and compares.
 struct Cursor {
-    int32_t pos;      // input position of the lane's pair in the batch being looked up
-    uint32_t u;       // its step
-    uint32_t ulo, ucnt;  // active iff u - ulo < ucnt
-    uint32_t ufirst;  // order 1: step at which the pair sits on the first byte of its quarter (context 0)
+    int32_t pos;      // input position of the first step of the lane's run in the batch being looked up
+    uint32_t u;       // that step
+    uint32_t ulo, ucnt;  // step u is active iff u - ulo < ucnt
+    uint32_t ufirst;  // order 1: step at which the state sits on the first byte of its quarter (context 0)
     int ringbase;
 };
 template <int MODE>
-__device__ __forceinline__ Cursor cursor_init(const Geo& g, int t, int j) {  // t = step within the batch
+__device__ __forceinline__ Cursor cursor_init(const Geo& g, int t, int j) {  // t = first step of the run within the batch
     Cursor c;
     c.u = (uint32_t)t;
     c.pos = pos_of<MODE>(g, t, j);
@@ -789,26 +790,35 @@ __device__ __forceinline__ void cursor_next(Cursor& c) {
     c.u += kBatch;
     c.pos -= MODE == MODE_O0 ? 4 * kBatch : kBatch;
 }
-// ring -> packed symbol of the cursor's pair (reads are unconditional: a stale ring byte is a valid table index)
+// ring -> packed symbols of the four steps of the cursor's run (reads are unconditional: a stale ring byte is a valid
+// table index).  Order 1: the context of step k is the symbol of step k+1 (the byte before it), five ring bytes in all.
 template <int MODE>
-__device__ __forceinline__ uint2 lookup_entry(const Cursor& c, const uint8_t* ring, const uint2* ent, int stride, bool& act) {
+__device__ __forceinline__ void lookup_run(const Cursor& c, const uint8_t* ring, const uint2* ent, int stride, uint2 (&e)[kRun],
+                                           bool (&act)[kRun]) {
     constexpr int mask = MODE == MODE_O0 ? kRingBytes - 1 : kRingBytes / 4 - 1;
-    act = c.u - c.ulo < c.ucnt;
-    const uint32_t sym = ring[c.ringbase + (c.pos & mask)];
-    if (MODE == MODE_O0) return ent[sym];
-    uint32_t ctx = ring[c.ringbase + ((c.pos - 1) & mask)];
-    if (c.u == c.ufirst) ctx = 0u;
-    const uint32_t idx = ctx * (uint32_t)stride + sym;
-    return ent[act ? idx : 0u];  // an inactive pair may hold a stale ring byte: no stray table reads
+    if (MODE == MODE_O0) {
+        uint32_t sym[kRun];
+#pragma unroll
+        for (int k = 0; k < kRun; k++) sym[k] = ring[(c.pos - 4 * k) & mask];
+#pragma unroll
+        for (int k = 0; k < kRun; k++) {
+            act[k] = c.u + (uint32_t)k - c.ulo < c.ucnt;
+            e[k] = ent[sym[k]];
+        }
+    } else {
+        uint32_t B[kRun + 1];
+#pragma unroll
+        for (int k = 0; k <= kRun; k++) B[k] = ring[c.ringbase + ((c.pos - k) & mask)];
+#pragma unroll
+        for (int k = 0; k < kRun; k++) {
+            act[k] = c.u + (uint32_t)k - c.ulo < c.ucnt;
+            const uint32_t ctx = c.u + (uint32_t)k == c.ufirst ? 0u : B[k + 1];
+            const uint32_t idx = ctx * (uint32_t)stride + B[k];
+            e[k] = ent[act[k] ? idx : 0u];  // an inactive step may hold a stale ring byte: no stray table reads
+        }
+    }
 }
 
-// Encoding#RansEncPutSymbol L46-71 for the 16 steps of a half batch, all four states (chain wave, rotating layout:
-// lane 16j + t holds the record of step t of state j).  The renormalisation test is arithmetic — the sign of
-// (x_max - 1) - x selects a byte shift (v_alignbyte) — because a compare + select through VCC needs two idle issue
-// slots between them on gfx950 (scripts/ubench/seq_bench.hip: 14.0 vs 18.3 cycles).
-// GENERAL: the half batch holds symbols with freq < 16, whose first renormalisation byte is certain (x >= L > x_max):
-// sm = 1 in the lanes of such records.
-// Returns the state after the half batch (valid in lane 15 of every row); lg = the state before this lane's step.
 __device__ __forceinline__ uint32_t shr_bytes(uint32_t x, uint32_t nbytes) {
 #ifdef HIP_SIM
     return x >> (8u * (nbytes & 3u));
@@ -816,73 +826,99 @@ __device__ __forceinline__ uint32_t shr_bytes(uint32_t x, uint32_t nbytes) {
     return __builtin_amdgcn_alignbyte(0u, x, nbytes);
 #endif
 }
+// Encoding#RansEncPutSymbol L46-71 on one expanded record (helper wave: the states between the logged ones)
+__device__ __forceinline__ uint32_t put_symbol(uint32_t x, const uint4 P, uint32_t& nbytes) {
+    const uint32_t small = P.w >> 31;             // freq < 16: the first renormalisation byte is certain (x >= L > x_max)
+    const uint32_t x1 = shr_bytes(x, small);
+    const uint32_t ren = (P.x - x1) >> 31;        // x1 > x_max - 1
+    nbytes = small + ren;
+    const uint32_t r = shr_bytes(x1, ren);
+    const uint32_t q = __umulhi(r, P.y) >> ((P.w >> 24) & 31u);  // q < 2^19, cmpl_freq < 2^12
+    return r + P.z + __umul24(q, P.w);
+}
+
+// DPP data movement of the helper wave's prefix sums (lanes without a source, or outside the row mask, read 0)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += dpp0<0x111>(v);        // row_shr:1
+    v += dpp0<0x112>(v);        // row_shr:2
+    v += dpp0<0x114>(v);        // row_shr:4
+    v += dpp0<0x118>(v);        // row_shr:8
+    v += dpp0<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp0<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t lane63(uint32_t v) {
 #ifdef HIP_SIM
-struct LogRegs {
-    uint32_t l0, l1, l2, l3;
-};
+    return __shfl(v, 63);
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+#endif
+}
+
+// Encoding#RansEncPutSymbol L46-71 for the 16 steps of a group, all four states (chain wave).  Lane 4q + s of a row
+// (q = 0..3: the row's four DPP banks) holds the records of steps 4q .. 4q+3 of state 3 - s; the states sit in bank
+// q - 1 before run q, move on with ONE row_ror:4 DPP move per four steps and are coded four steps in a row by the lane
+// that holds those records: 7 dependent vector instructions per step plus the move and its hazard slot once per four
+// (round 2 moved the state after every step: 9 issue slots per step instead of 7.5; scripts/ubench/step_bench.hip: 50.5 ->
+// 42.0 cycles per step).  The move of run q writes only bank q of lg, so after the group lg holds, in every lane, the
+// state before that lane's run: the log of a group leaves as one 4-byte LDS write per lane and the helper wave recomputes
+// the three states inside the run from it (put_symbol, 64 runs per instruction).  Every lane executes every run (three
+// of four compute garbage that is never read): a vector instruction costs the wave the same whatever its EXEC mask.
+// The renormalisation test is arithmetic - the sign of (x_max - 1) - x selects a byte shift (v_alignbyte) - because a
+// compare + select through VCC is no faster and ties up VCC.
+// General variant: the group holds symbols with freq < 16, whose first renormalisation byte is certain.
+#ifdef HIP_SIM
 template <bool GENERAL>
-__device__ __forceinline__ uint32_t rot_steps(uint32_t x, const uint4 P, uint32_t sm, LogRegs&, uint32_t& lg) {
+__device__ __forceinline__ uint32_t group_steps(uint32_t x, const uint4 (&P)[kRun], uint32_t& lg) {
     const int l = lane_id();
-    for (int tt = 0; tt < kSteps; tt++) {
-        const uint32_t xin = __shfl(x, (l & 48) | ((l - 1) & 15));  // row_ror:1
-        if (tt == (l & 15)) lg = xin;
-        uint32_t p = xin;
-        if (GENERAL) p = shr_bytes(p, sm);
-        const uint32_t xr = shr_bytes(p, (P.x - p) >> 31);
-        const uint32_t qq = __umulhi(xr, P.y) >> ((P.w >> 24) & 31u);  // qq < 2^19, cmpl_freq < 2^12
-        x = xr + P.z + __umul24(qq, P.w);
+    for (int q = 0; q < 4; q++) {
+        const uint32_t xin = __shfl(x, (l & 48) | ((l - 4) & 15));  // row_ror:4
+        if (((l >> 2) & 3) == q) lg = xin;
+        uint32_t y = lg, nb;
+        for (int k = 0; k < kRun; k++) {
+            uint4 R = P[k];
+            if (!GENERAL) R.w &= 0x7FFFFFFFu;
+            y = put_symbol(y, R, nb);
+        }
+        x = y;
     }
     return x;
 }
 #else
-// Straight-line assembly, 8 vector instructions per step (9 in a general half batch).  A DPP operand read straight
-// behind the VALU write of the same register returns the OLD value on gfx950 (scripts/ubench/rot_bench.hip: wrong
-// states without a gap, right ones with one instruction in between), hence the s_nop in front of every move.  The
-// move of step t writes only the bank (4 lanes) of lane t, into log register t & 3: a lane's own "state before my
-// step" is written exactly once per half batch, to register (lane & 3).  The shift count of the quotient is byte 3
-// of the record's last word (SDWA), the 24-bit multiply ignores that byte.  Three selects under constant lane masks
-// then gather the four log registers into one (register k is the right one in the lanes with lane & 3 == k).
-struct LogRegs {  // live across half batches only so that they need no initialisation per half
-    uint32_t l0, l1, l2, l3;
-};
-#define ROT_CORE(SRC)                                                                                              \
-    "v_sub_u32 %[t], %[a], %[" #SRC "]\n\t"                                                                        \
-    "v_lshrrev_b32 %[t], 31, %[t]\n\t"                                                                             \
-    "v_alignbyte_b32 %[r], 0, %[" #SRC "], %[t]\n\t"                                                               \
-    "v_mul_hi_u32 %[m], %[r], %[b]\n\t"                                                                            \
-    "v_lshrrev_b32_sdwa %[m], %[d], %[m] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"   \
-    "v_mul_u32_u24 %[m], %[m], %[d]\n\t"                                                                           \
-    "v_add3_u32 %[x], %[r], %[c], %[m]\n\t"
-#define ROT_STEP(LG, BK)                                                                                           \
-    "s_nop 0\n\t"                                                                                                  \
-    "v_mov_b32_dpp %[" #LG "], %[x] row_ror:1 row_mask:0xf bank_mask:" #BK "\n\t" ROT_CORE(LG)
-#define ROT_STEP_G(LG, BK)                                                                                         \
-    "s_nop 0\n\t"                                                                                                  \
-    "v_mov_b32_dpp %[" #LG "], %[x] row_ror:1 row_mask:0xf bank_mask:" #BK "\n\t"                                  \
-    "v_alignbyte_b32 %[p], 0, %[" #LG "], %[sm]\n\t" ROT_CORE(p)
-#define ROT4(STEP, BK) STEP(l0, BK) STEP(l1, BK) STEP(l2, BK) STEP(l3, BK)
-#define ROT16(STEP) ROT4(STEP, 0x1) ROT4(STEP, 0x2) ROT4(STEP, 0x4) ROT4(STEP, 0x8)
-#define ROT_SELECT                                                \
-    "v_cndmask_b32_e64 %[lg], %[l0], %[l1], %[k1]\n\t"            \
-    "v_cndmask_b32_e64 %[lg], %[lg], %[l2], %[k2]\n\t"            \
-    "v_cndmask_b32_e64 %[lg], %[lg], %[l3], %[k3]\n\t"
-// Both variants in ONE asm statement, the choice made by a scalar branch inside it: two statements under a C++ branch
-// leave the compiler free to keep the state and the log in different registers on the two paths, and it then moves five
-// registers at every join (20 cycles per 16 steps).  gs = the half batch's general flag, already in a scalar register.
-// Measured and dropped: folding the rotate into the step's last add (v_add_u32_dpp of q * cmpl_freq with a DPP-moved
-// r + bias, 7 dependent instructions instead of 8 but 9 issued instead of 8) makes ONE block faster (8.40 -> 8.24 ms
-// for 1.5 MB) and the full launch slower (QS blocks 13.6 -> 15.2 ms): with the other waves of the launch on
-// the same SIMD a step is bound by vector issue slots, not by the chain's latency.
-__device__ __forceinline__ uint32_t rot_steps_both(uint32_t x, const uint4 P, uint32_t sm, uint32_t gs, LogRegs& G, uint32_t& lg) {
+// A DPP operand read straight behind the VALU write of the same register returns the OLD value on gfx950
+// (scripts/ubench/rot_bench.hip), hence the s_nop in front of every move.  The shift count of the quotient is byte 3 of
+// the record's last word (SDWA; the shift reads its low five bits), the 24-bit multiply ignores that byte.
+#define QSTEP(IN, K)                                                                                                 \
+    "v_sub_u32 %[t], %[a" #K "], %[" #IN "]\n\t"                                                                     \
+    "v_lshrrev_b32 %[t], 31, %[t]\n\t"                                                                               \
+    "v_alignbyte_b32 %[r], 0, %[" #IN "], %[t]\n\t"                                                                  \
+    "v_mul_hi_u32 %[m], %[r], %[b" #K "]\n\t"                                                                        \
+    "v_lshrrev_b32_sdwa %[m], %[d" #K "], %[m] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t" \
+    "v_mul_u32_u24 %[m], %[m], %[d" #K "]\n\t"                                                                       \
+    "v_add3_u32 %[x], %[r], %[c" #K "], %[m]\n\t"
+#define QSTEP_G(IN, K)                             \
+    "v_lshrrev_b32 %[t], 31, %[d" #K "]\n\t"       \
+    "v_alignbyte_b32 %[p], 0, %[" #IN "], %[t]\n\t" QSTEP(p, K)
+#define QRUN(STEP, BK)                                                               \
+    "s_nop 0\n\t"                                                                    \
+    "v_mov_b32_dpp %[lg], %[x] row_ror:4 row_mask:0xf bank_mask:" #BK "\n\t" STEP(lg, 0) STEP(x, 1) STEP(x, 2) STEP(x, 3)
+#define QGROUP(STEP) QRUN(STEP, 0x1) QRUN(STEP, 0x2) QRUN(STEP, 0x4) QRUN(STEP, 0x8)
+// Both variants in ONE asm statement, the choice made by a scalar branch inside it (two statements under a C++ branch
+// leave the compiler free to keep the state in different registers on the two paths and to move registers at every join).
+// gs = the group's general flag, already in a scalar register.
+__device__ __forceinline__ uint32_t group_steps_both(uint32_t x, const uint4 (&P)[kRun], uint32_t gs, uint32_t& lg) {
     uint32_t t, r, m, p;
-    const unsigned long long k1 = 0x2222222222222222ull, k2 = 0x4444444444444444ull, k3 = 0x8888888888888888ull;
     asm volatile("s_cmp_eq_u32 %[gs], 0\n\t"
-                 "s_cbranch_scc1 .LrotF_%=\n\t" ROT16(ROT_STEP_G) "s_branch .LrotD_%=\n"
-                 ".LrotF_%=:\n\t" ROT16(ROT_STEP) ".LrotD_%=:\n\t" ROT_SELECT
-                 : [x] "+v"(x), [l0] "+v"(G.l0), [l1] "+v"(G.l1), [l2] "+v"(G.l2), [l3] "+v"(G.l3), [t] "=&v"(t),
-                   [r] "=&v"(r), [m] "=&v"(m), [p] "=&v"(p), [lg] "=&v"(lg)
-                 : [a] "v"(P.x), [b] "v"(P.y), [c] "v"(P.z), [d] "v"(P.w), [sm] "v"(sm), [gs] "s"(gs), [k1] "s"(k1), [k2] "s"(k2),
-                   [k3] "s"(k3)
+                 "s_cbranch_scc1 .LgrpF_%=\n\t" QGROUP(QSTEP_G) "s_branch .LgrpD_%=\n"
+                 ".LgrpF_%=:\n\t" QGROUP(QSTEP) ".LgrpD_%=:\n\t"
+                 : [x] "+v"(x), [lg] "+v"(lg), [t] "=&v"(t), [r] "=&v"(r), [m] "=&v"(m), [p] "=&v"(p)
+                 : [a0] "v"(P[0].x), [b0] "v"(P[0].y), [c0] "v"(P[0].z), [d0] "v"(P[0].w), [a1] "v"(P[1].x), [b1] "v"(P[1].y),
+                   [c1] "v"(P[1].z), [d1] "v"(P[1].w), [a2] "v"(P[2].x), [b2] "v"(P[2].y), [c2] "v"(P[2].z), [d2] "v"(P[2].w),
+                   [a3] "v"(P[3].x), [b3] "v"(P[3].y), [c3] "v"(P[3].z), [d3] "v"(P[3].w), [gs] "s"(gs)
                  : "scc");
     return x;
 }
@@ -890,10 +926,11 @@ __device__ __forceinline__ uint32_t rot_steps_both(uint32_t x, const uint4 P, ui
 
 // Collective over both waves.  Returns (in the helper wave) the payload length including the 16 state bytes, or a
 // negative code.  The payload is written downwards from pend.
-// Iteration i: the chain wave runs batch i from stage[i&1] and logs into xs[i&1]; the helper wave turns the log of batch
-// i-1 into bytes, expands the symbols of batch i+1 into stage[(i+1)&1] and looks up the symbols of batch i+2; one
-// barrier.  Input reaches the helper through an LDS ring that is refilled with 16-byte loads a whole chunk (16
-// batches) before it is needed, so that no iteration waits for global memory.
+// Iteration i: the chain wave runs batch i (records of group G+1 are fetched while group G runs) and logs into xs[i&1];
+// the helper wave turns the log of batch i-1 into bytes (re-reading that batch's records from the staging area),
+// expands the symbols of batch i+2 into stage[(i+2)&3] and looks up the symbols of batch i+3; one barrier.  Input
+// reaches the helper through an LDS ring that is refilled with 16-byte loads a whole chunk (4 batches) before it is
+// needed, so that no iteration waits for global memory.
 // In-kernel cycle stamps exist only in the profiling build (make prof -> libcramgpu_prof.so): s_memtime shares the
 // LDS counter and, being out of order, makes the compiler wait for ALL outstanding LDS reads at every use.
 #ifdef CRAMGPU_PROF_BUILD
@@ -909,9 +946,8 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
     const int32_t n = UNIFORM(n_), stride = UNIFORM(stride_), room = UNIFORM(room_);  // arrive in vector registers
     const int l = lane_id();
     const bool helper = wave_id() == 1;
-    const int t = l >> 2, j = 3 - (l & 3);   // helper lane -> (step, state): lane order = emission order
-    const int slot = j * kStageRow + t;      // its record in the staging area
-    const int cslot = (l >> 4) * kStageRow + (l & 15);  // chain lane 16j + t -> the same record
+    const int js = l & 3, j = 3 - js;        // helper lane -> state: lane order = emission order within a step
+    const int cl = l & 15;                   // chain lane within its row (the four rows do the same work)
     Geo g;
     g.n = n;
     g.q = n >> 2;
@@ -920,29 +956,31 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
     const int32_t nbatch = (g.U + kBatch - 1) / kBatch;
     const int32_t limit = room - 16;
     const uint4 ident = make_uint4(0x7FFFFFFFu, 0u, 0u, 0u);  // identity step for inactive (step, state) pairs (x < 2^31)
-    uint32_t x = RANS_BYTE_L;  // chain wave: the state of row j, on its way round the row
-    LogRegs logs{0u, 0u, 0u, 0u};
-    // helper wave, per half batch: x_max - 1 and the word with the freq < 16 flag of the records of batches i+1, i, i-1
-    // at the start of iteration i (Ax/Aw[0], [1], [2]: what the byte emission of a batch needs of its records, kept
-    // until the chain has logged that batch), looked-up symbol of batch i+3
-    uint32_t Ax[3][kHalves], Aw[3][kHalves];
-    uint2 e2[kHalves];
-    bool act2[kHalves];
-    Cursor cur[kHalves];
+    uint32_t x = RANS_BYTE_L;  // chain wave: the states, on their way round the row
+    uint32_t lg = 0;
+    uint2 e2[kRun];     // helper wave: looked-up symbols of batch i+3
+    bool act2[kRun];
 #pragma unroll
-    for (int h = 0; h < kHalves; h++) {
-#pragma unroll
-        for (int q = 0; q < 3; q++) Ax[q][h] = ident.x, Aw[q][h] = 0u;
-        e2[h] = make_uint2(0u, 0u);
-        act2[h] = false;
-        cur[h] = cursor_init<MODE>(g, h * kSteps + t, j);
-    }
+    for (int k = 0; k < kRun; k++) e2[k] = make_uint2(0u, 0u), act2[k] = false;
+    Cursor cur = cursor_init<MODE>(g, kRun * (l >> 2), j);
+    const uint32_t m1 = js >= 1 ? ~0u : 0u, m2 = js >= 2 ? ~0u : 0u;
     ChunkRegs CR;
     int32_t run = 0;
     bool failed = false;
-    // Staging is three batches deep: in iteration i the chain wave runs batch i from registers and fetches the records
-    // of batch i+1 (staged in iteration i-1, visible since the barrier that ended it) while the helper stages batch
-    // i+2 — no iteration of the chain begins by waiting for an LDS round trip.
+    // expand the looked-up run into the staging buffer sb, general flags of its four groups
+    auto stage_run = [&](int sb) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < kRun; k++) {
+            const uint4 A = act2[k] ? expand_symbol(e2[k]) : ident;
+            L->p3.stage[sb][l * kRun + k] = A;
+            any |= A.w;
+        }
+        const unsigned long long sm = __ballot((int32_t)any < 0);
+        if (l == 0)
+            L->p3.gflag[sb] = ((sm & 0xFFFFull) ? 1u : 0u) | ((sm & 0xFFFF0000ull) ? 2u : 0u) | ((sm & 0xFFFF00000000ull) ? 4u : 0u) |
+                              ((sm >> 48) ? 8u : 0u);
+    };
     if (helper) {
         chunk_load<MODE>(src, g, 0, l, CR);
         chunk_store<MODE>(CR, L->p3.ring, L->dmap);
@@ -950,98 +988,91 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
         WSYNC();
 #pragma unroll
         for (int b0 = 0; b0 < 2; b0++) {  // batches 0 and 1
-#pragma unroll
-            for (int h = 0; h < kHalves; h++) {
-                bool act0;
-                const uint2 e0 = lookup_entry<MODE>(cur[h], L->p3.ring, ent, stride, act0);
-                cursor_next<MODE>(cur[h]);
-                const uint4 A = act0 ? expand_symbol(e0) : ident;
-                const unsigned long long sm = __ballot((int32_t)A.w < 0);
-                L->p3.stage[b0][h][slot] = A;
-                if (l == 0) L->p3.gflag[b0][h] = sm != 0 ? 1u : 0u;  // this half needs the general chain
-                Ax[1 - b0][h] = A.x, Aw[1 - b0][h] = A.w;  // batch 0 -> slot 1, batch 1 -> slot 0
-            }
+            lookup_run<MODE>(cur, L->p3.ring, ent, stride, e2, act2);
+            cursor_next<MODE>(cur);
+            stage_run(b0);
         }
-#pragma unroll
-        for (int h = 0; h < kHalves; h++) {
-            e2[h] = lookup_entry<MODE>(cur[h], L->p3.ring, ent, stride, act2[h]);
-            cursor_next<MODE>(cur[h]);
-        }
+        lookup_run<MODE>(cur, L->p3.ring, ent, stride, e2, act2);
+        cursor_next<MODE>(cur);
     }
     pair_barrier();
 #ifndef HIP_SIM
     if (!helper) __builtin_amdgcn_s_setprio(3);  // the chain wave is the critical path of the block
 #endif
-    // chain wave: records and flags of the batch about to run
-    uint4 Pc[kHalves];
-    uint32_t fc[kHalves];
+    // chain wave: records of the group about to run, flags of the batch about to run
+    uint4 Pc[kRun];
+    uint32_t fc = 0;
     if (!helper) {
+        fc = L->p3.gflag[0];
 #pragma unroll
-        for (int h = 0; h < kHalves; h++) {
-            fc[h] = L->p3.gflag[0][h];
-            Pc[h] = L->p3.stage[0][h][cslot];
-        }
+        for (int k = 0; k < kRun; k++) Pc[k] = L->p3.stage[0][cl * kRun + k];
     }
-    unsigned long long busy = 0, busy2 = 0, ngen = 0;
-    int sb = 0;  // staging buffer of batch i (i mod 3)
+    unsigned long long busy = 0;
     for (int32_t i = 0; i <= nbatch; i++) {
-        const int buf = i & 1;
-        const int sb1 = sb == 2 ? 0 : sb + 1, sb2 = sb1 == 2 ? 0 : sb1 + 1;
+        const int sb = i & (kStageBufs - 1), sb1 = (i + 1) & (kStageBufs - 1), sb2 = (i + 2) & (kStageBufs - 1);
         const long long tb = prof ? clock64() : 0;
         if (!helper) {
             if (i < nbatch) {
-                // batch i+1's records and flags: the reads land while batch i runs
-                uint4 Pn[kHalves];
-                uint32_t fn[kHalves];
+                const uint32_t fn = L->p3.gflag[sb1];  // the next batch's flags land while this one runs
+                const uint32_t gsb = (uint32_t)UNIFORM(fc);
 #pragma unroll
-                for (int h = 0; h < kHalves; h++) {
-                    fn[h] = L->p3.gflag[sb1][h];
-                    Pn[h] = L->p3.stage[sb1][h][cslot];
-                }
-                // the general flags of the four half batches into scalar registers up front: a flag read right in front of its
-                // branch makes the branch wait for the vector-to-scalar hand-over every time
-                uint32_t gs[kHalves];
+                for (int G = 0; G < kGroups; G++) {
+                    // records of the next group (the first one of batch i+1 behind the last one of batch i)
+                    uint4 Pn[kRun];
+                    const uint4* nx = G + 1 < kGroups ? &L->p3.stage[sb][(kGroup * (G + 1) + cl) * kRun] : &L->p3.stage[sb1][cl * kRun];
 #pragma unroll
-                for (int h = 0; h < kHalves; h++) {
+                    for (int k = 0; k < kRun; k++) Pn[k] = nx[k];
 #ifdef HIP_SIM
-                    gs[h] = UNIFORM(fc[h]);
+                    x = ((gsb >> G) & 1u) ? group_steps<true>(x, Pc, lg) : group_steps<false>(x, Pc, lg);
 #else
-                    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(gs[h]) : "v"(fc[h]));  // volatile: stays up here
+                    x = group_steps_both(x, Pc, (gsb >> G) & 1u, lg);
 #endif
-                }
+                    L->p3.xs[i & 1][kGroup * G + cl] = lg;
 #pragma unroll
-                for (int h = 0; h < kHalves; h++) {
-                    const bool general = gs[h] != 0;
-                    if (prof && h == 0) busy2 += (unsigned long long)(clock64() - tb);
-                    if (prof && general) ngen++;
-                    uint32_t lg;
-#ifdef HIP_SIM
-                    x = general ? rot_steps<true>(x, Pc[h], Pc[h].w >> 31, logs, lg) : rot_steps<false>(x, Pc[h], 0u, logs, lg);
-#else
-                    x = rot_steps_both(x, Pc[h], Pc[h].w >> 31, gs[h], logs, lg);
-#endif
-                    L->p3.xs[buf][h][l] = lg;
+                    for (int k = 0; k < kRun; k++) Pc[k] = Pn[k];
                 }
-                if ((l & 15) == 15) L->p3.fin[l >> 4] = x;
-#pragma unroll
-                for (int h = 0; h < kHalves; h++) Pc[h] = Pn[h], fc[h] = fn[h];
+                if (cl >= 12) L->p3.fin[3 - (cl & 3)] = x;  // bank 3 holds the states after a group
+                fc = fn;
             }
         } else {
-            // the log of batch i-1 (garbage in iteration 0, masked below)
-            uint32_t xv[kHalves];
+            // bytes of batch i-1 in the reference's emission order: step, then state 3,2,1,0 = run, step of the run, lane & 3
+            if (i > 0) {
+                uint32_t xv = L->p3.xs[(i - 1) & 1][l];
+                uint4 R[kRun];
 #pragma unroll
-            for (int h = 0; h < kHalves; h++)
-                xv[h] = L->p3.xs[buf ^ 1][h][j * kSteps + t];
-            // batch i+2: expand the symbols looked up one iteration ago
-            uint32_t Anx[kHalves], Anw[kHalves];
+                for (int k = 0; k < kRun; k++) R[k] = L->p3.stage[(i - 1) & (kStageBufs - 1)][l * kRun + k];
+                uint32_t lo16[kRun], nbp = 0;  // byte counts of the four steps, one per byte of nbp
 #pragma unroll
-            for (int h = 0; h < kHalves; h++) {
-                const uint4 An = act2[h] ? expand_symbol(e2[h]) : ident;
-                const unsigned long long sm = __ballot((int32_t)An.w < 0);
-                L->p3.stage[sb2][h][slot] = An;
-                if (l == 0) L->p3.gflag[sb2][h] = sm != 0 ? 1u : 0u;
-                Anx[h] = An.x, Anw[h] = An.w;
+                for (int k = 0; k < kRun; k++) {
+                    uint32_t nb;
+                    lo16[k] = xv;
+                    xv = put_symbol(xv, R[k], nb);
+                    nbp |= nb << (8 * k);
+                }
+                // positions: runs in lane order; inside a run step by step, inside a step the quad's lanes in order
+                uint32_t S = nbp;  // inclusive scan over the quad, all four steps at once (a count is at most 2)
+                S += dpp0<0x90>(S) & m1;   // quad_perm:[0,0,1,2]
+                S += dpp0<0x44>(S) & m2;   // quad_perm:[0,1,0,1]
+                const uint32_t Qp = dpp0<0xFF>(S);  // quad totals per step
+                const uint32_t Bp = S - nbp;        // bytes of the lower lanes of the quad per step
+                const uint32_t I = wave_incl_scan((nbp * 0x01010101u) >> 24);
+                const int32_t tot = (int32_t)lane63(I);
+                uint32_t acc = (uint32_t)run + dpp0<0xFF>(I) - ((Qp * 0x01010101u) >> 24);  // bytes in front of the quad's run
+                if (run + tot > limit) failed = true;
+                if (!failed) {
+#pragma unroll
+                    for (int k = 0; k < kRun; k++) {
+                        const uint32_t nb = (nbp >> (8 * k)) & 0xFFu;
+                        const int32_t idx = (int32_t)(acc + ((Bp >> (8 * k)) & 0xFFu));
+                        if (nb >= 1) pend[-1 - idx] = (uint8_t)lo16[k];
+                        if (nb == 2) pend[-2 - idx] = (uint8_t)(lo16[k] >> 8);
+                        acc += (Qp >> (8 * k)) & 0xFFu;
+                    }
+                    run += tot;
+                }
             }
+            // batch i+2: expand the symbols looked up one iteration ago
+            stage_run(sb2);
             // input ring: chunk c (kChunkBatches batches) is needed from iteration c * kChunkBatches - 3 on (the lookup
             // of batch i + 3 below); it is written at (c - 1) * kChunkBatches from the registers that were loaded one
             // chunk of iterations earlier, and the next chunk's loads are issued
@@ -1051,51 +1082,21 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
                 WSYNC();
             }
             // batch i+3: symbol lookup (the table reads land while this wave is at the barrier)
-#pragma unroll
-            for (int h = 0; h < kHalves; h++) {
-                e2[h] = lookup_entry<MODE>(cur[h], L->p3.ring, ent, stride, act2[h]);
-                cursor_next<MODE>(cur[h]);
-            }
-            // bytes of batch i-1 in the reference's emission order (state 3,2,1,0 per step = lane order)
-#pragma unroll
-            for (int h = 0; h < kHalves; h++) {
-                const bool small = (int32_t)Aw[2][h] < 0;
-                const uint32_t x1 = small ? xv[h] >> 8 : xv[h];
-                int nb = (small ? 1 : 0) + (x1 > Ax[2][h] ? 1 : 0);
-                if (i == 0) nb = 0;
-                const unsigned long long m1 = __ballot(nb >= 1), m2 = __ballot(nb == 2);
-                const int32_t tot = __popcll(m1) + __popcll(m2);
-                if (run + tot > limit) failed = true;
-                if (!failed) {
-                    const int32_t idx = run + (int32_t)(mbcnt(m1) + mbcnt(m2));
-                    if (nb >= 1) pend[-1 - idx] = (uint8_t)xv[h];
-                    if (nb == 2) pend[-2 - idx] = (uint8_t)(xv[h] >> 8);
-                    run += tot;
-                }
-                Ax[2][h] = Ax[1][h], Aw[2][h] = Aw[1][h];
-                Ax[1][h] = Ax[0][h], Aw[1][h] = Aw[0][h];
-                Ax[0][h] = Anx[h], Aw[0][h] = Anw[h];
-            }
+            lookup_run<MODE>(cur, L->p3.ring, ent, stride, e2, act2);
+            cursor_next<MODE>(cur);
         }
         if (prof) busy += (unsigned long long)(clock64() - tb);
         pair_barrier();
-        sb = sb1;
     }
 #ifndef HIP_SIM
     if (!helper) __builtin_amdgcn_s_setprio(0);
 #endif
     if (prof) {
-        if (!helper && l == 0) {
-            L->p3.cbusy = busy;
-            L->p3.cbusy2 = busy2;
-            L->p3.cgen = ngen;
-        }
+        if (!helper && l == 0) L->p3.cbusy = busy;
         pair_barrier();
         if (helper && l == 0) {
             prof[2] = busy;
             prof[3] = L->p3.cbusy;
-            prof[5] = L->p3.cbusy2;
-            prof[6] = L->p3.cgen;
             prof[4] = (unsigned long long)nbatch;
         }
     }
@@ -1147,7 +1148,7 @@ __device__ __attribute__((noinline)) Prep prep_o0(Blk B) {
     uint8_t* tab = lds.tab;
     uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);    // 256 words
     uint2* ent0 = reinterpret_cast<uint2*>(tab + 1024);  // 256 x 8 B
-    uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
+    uint32_t* rep0 = reinterpret_cast<uint32_t*>(lds_big());  // the coding loop's buffers are free until phase 3
     hist_o0(B.src, B.n, cnt0, rep0);
     Prep r{MODE_O0, 256, 1024, 0, 0};
     if (!helper) return r;
@@ -1166,7 +1167,7 @@ __device__ __attribute__((noinline)) Prep prep_o1(Blk B) {
     EncFixedLds* L = &lds;
     uint8_t* tab = lds.tab;
     uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);
-    uint32_t* rep0 = reinterpret_cast<uint32_t*>(tab + 1024 + 2048);
+    uint32_t* rep0 = reinterpret_cast<uint32_t*>(lds_big());
     hist_o0(B.src, B.n, cnt0, rep0);
     // dense alphabet = present symbols plus 0 (context 0 always exists); both waves derive its size, one writes the maps
     uint32_t present = 0, mine = 0;

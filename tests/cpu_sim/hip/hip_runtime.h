@@ -160,7 +160,7 @@ inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t m, uint32_t base) {
     uint32_t lt = l <= 32 ? 0u : ((1u << (l - 32)) - 1);
     return base + (uint32_t)__builtin_popcount(m & lt);
 }
-inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool) {
     int l = hipsim::lane(), s;
     if (ctrl <= 0xFF)
         s = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
@@ -170,10 +170,17 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, boo
         s = (l & ~15) | (15 - (l & 15));
     else if (ctrl >= 0x111 && ctrl <= 0x11F)  // row_shr:n, bound_ctrl off: lanes without a source keep `old`
         s = (l & 15) >= (ctrl - 0x110) ? l - (ctrl - 0x110) : -1;
+    else if (ctrl >= 0x121 && ctrl <= 0x12F)  // row_ror:n
+        s = (l & ~15) | ((l - (ctrl - 0x120)) & 15);
+    else if (ctrl == 0x142)  // row_bcast:15: lane 15 of a row to the next row
+        s = l >= 16 ? (l & ~15) - 1 : -1;
+    else if (ctrl == 0x143)  // row_bcast:31: lane 31 to rows 2 and 3
+        s = l >= 32 ? 31 : -1;
     else
         abort();
+    const bool enabled = ((row_mask >> (l >> 4)) & 1) && ((bank_mask >> ((l >> 2) & 3)) & 1);
     int r = (int)(uint32_t)hipsim::exchange((uint32_t)src, s);
-    return s < 0 ? old : r;
+    return (s < 0 || !enabled) ? old : r;
 }
 inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
