@@ -323,7 +323,7 @@ int rans_run(cramgpu_ctx* c, LaunchRes& r, bool encode, const uint8_t* d_in, uin
     }
     HIPCHK(r.tickets.reserve(kTicketSlots));
     if (encode)
-        HIPCHK(r.enc_gs.reserve((size_t)groups * ENC_GSCRATCH_BYTES));
+        HIPCHK(r.enc_gs.reserve((size_t)((groups + 3) & ~3) * ENC_GSCRATCH_BYTES));  // four slots to a workgroup
     else
         HIPCHK(r.dec_gs.reserve((size_t)groups * DEC_GSCRATCH_BYTES));
     uint32_t* ticket = r.tickets.p + (r.ticket_next++ % kTicketSlots);
@@ -356,11 +356,40 @@ int rans_run(cramgpu_ctx* c, LaunchRes& r, bool encode, const uint8_t* d_in, uin
             for (int32_t i = 1; i < n; i++)
                 if (blocks[i].in_len > blocks[big].in_len) big = i;
             const unsigned long long* r = h.data() + (size_t)big * 8;
-            fprintf(stderr, "[cramgpu prof] largest block %d B: prep %llu cyc, stream %llu cyc, helper busy %llu, chain busy %llu, "
-                            "batches %llu (per step: stream %.1f, helper %.1f, chain %.1f of which record reads %.1f; general half batches %llu)\n",
-                    blocks[big].in_len, r[0], r[1], r[2], r[3], r[4], r[4] ? (double)r[1] / (32.0 * r[4]) : 0.0,
-                    r[4] ? (double)r[2] / (32.0 * r[4]) : 0.0, r[4] ? (double)r[3] / (32.0 * r[4]) : 0.0,
-                    r[4] ? (double)r[5] / (32.0 * r[4]) : 0.0, r[6]);
+            {   // when the blocks began and ended (100 MHz stamps), how long their phases took
+                unsigned long long t_first = ~0ull, t_last = 0, pmax = 0, smax = 0, smin = ~0ull;
+                double psum = 0, ssum = 0;
+                int cnt = 0, late = 0;
+                for (int32_t i = 0; i < n; i++) {
+                    const unsigned long long* q = h.data() + (size_t)i * 8;
+                    if (blocks[i].in_len < blocks[big].in_len / 2 || !q[7]) continue;
+                    const unsigned long long dur = (unsigned long long)((double)(q[0] + q[1]) * (double)q[6] / (double)(q[1] ? q[1] : 1));
+                    t_first = std::min(t_first, q[7] - dur);
+                    t_last = std::max(t_last, q[7]);
+                    pmax = std::max(pmax, q[0]);
+                    smax = std::max(smax, q[1]);
+                    smin = std::min(smin, q[1]);
+                    psum += (double)q[0];
+                    ssum += (double)q[1];
+                    cnt++;
+                }
+                for (int32_t i = 0; i < n; i++) {
+                    const unsigned long long* q = h.data() + (size_t)i * 8;
+                    if (blocks[i].in_len < blocks[big].in_len / 2 || !q[7]) continue;
+                    const unsigned long long dur = (unsigned long long)((double)(q[0] + q[1]) * (double)q[6] / (double)(q[1] ? q[1] : 1));
+                    if (q[7] - dur > t_first + 50000) late++;  // began more than 0.5 ms after the first
+                }
+                if (cnt)
+                    fprintf(stderr, "[cramgpu prof] %d long blocks: first begins to last ends %.3f ms; prep mean %.0f max %llu cyc; stream mean %.0f "
+                                    "min %llu max %llu cyc; %d began > 0.5 ms after the first\n",
+                            cnt, (double)(t_last - t_first) * 1e-5, psum / cnt, pmax, ssum / cnt, smin, smax, late);
+            }
+            // HW_ID: wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13
+            fprintf(stderr, "[cramgpu prof] largest block %d B: prep %llu cyc, stream %llu cyc, helper busy %llu, batches %llu "
+                            "(per step: stream %.1f, helper %.1f); chain wave on SIMD %llu, helper on SIMD %llu (CU %llu / %llu); "
+                            "batch-times the chain row stood still during this block: %llu; shader clock over phase 3: %.0f MHz\n",
+                    blocks[big].in_len, r[0], r[1], r[2], r[4], r[4] ? (double)r[1] / (64.0 * r[4]) : 0.0,
+                    r[4] ? (double)r[2] / (64.0 * r[4]) : 0.0, (r[3] >> 36) & 3, (r[3] >> 4) & 3, (r[3] >> 40) & 15, (r[3] >> 8) & 15, r[5], r[6] ? 100.0 * (double)r[1] / (double)r[6] : 0.0);
         }
     } else {
         a.gscratch = r.dec_gs.p;

@@ -8,31 +8,29 @@
 //
 // Execution model.  A CRAM block is one rANS stream whose four interleaved states form four strictly serial
 // dependency chains; byte identity forbids re-blocking, so the only parallelism inside a block is (a) the four
-// states and (b) everything that does not depend on the states.  A lone wave issues a vector instruction that depends on
-// its predecessor every 6 cycles (an independent one every 4; scripts/ubench/dec_bench.hip, lat_bench.hip), so the time
-// of a block is (instructions on the chain's critical path per step) x 6 cycles x steps: everything that is not the
-// chain is moved OFF the chain's wave.  The kernel is a resident grid of two-wave workgroups pulling blocks (longest first)
-// from a ticket counter:
-//   wave 1 ("helper")  1. histograms the input (LDS counters, lane-replicated for small alphabets),
-//                      2. normalises, serialises the frequency table, builds packed encoder symbols (a row per lane),
-//                      3. per batch of 64 coding steps (four groups of 16): fetches the symbol/context bytes, looks the symbols up and
-//                         expands them into a 16-byte record per (step, state) in an LDS staging buffer; turns the
-//                         states the chain logged for the previous batch into output bytes, placed with a
-//                         ballot/popcount prefix in the reference's emission order (state 3,2,1,0 per step) and
-//                         written from the end of the slot downwards, which realises Utils#reverse for free.
-//   wave 0 ("chain")   the "rotating" chain: state j lives in DPP row j (lanes 16j..16j+15) and step u of a half batch
-//                      runs in lane 16j + (u & 15) on THAT lane's own 16-byte record (one LDS read per lane per 16
-//                      steps instead of one per step); the state moves to the next lane with a row_ror:1 DPP move whose
-//                      bank mask leaves "state before my step" in one of four log registers, so that the log of a half
-//                      batch leaves as ONE 4-byte LDS write per lane.  Every lane executes every step (15 of 16 compute
-//                      garbage that is never read): a vector instruction costs the wave the same whatever its EXEC
-//                      mask, so idle lanes cost nothing and the per-step LDS traffic of a lane-resident state
-//                      is what goes away.  Per step: the DPP move, compare, conditional byte shift, mul_hi, shift,
-//                      24-bit multiply, add — Encoding#RansEncPutSymbol with everything state-independent removed.
-// The two waves meet at one workgroup barrier per batch; the staging area is triple buffered (the helper expands batch
-// i+2 while the chain runs batch i and prefetches the records of batch i+1), the log double buffered.
-// Order-1 tables live in LDS over the compacted alphabet (present symbols + 0) when n*(n|1)*12 B fits the table
-// region, else (same dense layout) in a per-workgroup global scratch.
+// states and (b) everything that does not depend on the states.  One wave issues a vector instruction every 4.4-5.4
+// cycles whether it depends on its predecessor or not (scripts/ubench/step_bench.hip), so the time of a block is (vector
+// instructions the chain's wave issues per step) x ~5 cycles x steps: everything that is not the chain is moved OFF the
+// chain's wave, and since a vector instruction costs the same whatever its lanes do, ONE chain wave serves the chains of
+// four blocks at once (a block per 16-lane DPP row).  The kernel is a resident grid of nine-wave workgroups, each with
+// four "slots" that pull blocks (longest first) from a ticket counter independently of each other:
+//   waves 2s, 2s+1     the two waves of slot s.  Both histogram the slot's block (LDS counters, lane-replicated for
+//   ("aux", "helper")  small alphabets); the helper wave then normalises, serialises the frequency table, builds packed
+//                      encoder symbols (a row per lane) and, per batch of 64 coding steps (four groups of 16), fetches the
+//                      symbol/context bytes, looks the symbols up, expands them into a 16-byte record per (step, state)
+//                      in an LDS staging buffer, and turns the states the chain logged for an earlier batch into output
+//                      bytes, placed with DPP prefix sums in the reference's emission order (state 3,2,1,0 per step) and
+//                      written from the end of the slot downwards, which realises Utils#reverse for free.
+//   wave 8 ("chain")   row s of the wave carries the four states of slot s's block: lane 4q + t of the row holds the
+//                      records of steps 4q .. 4q+3 (of a group of 16) of state 3 - t, the states move four lanes per
+//                      run (row_ror:4 DPP move) and are coded four steps in a row by the lane that holds those records;
+//                      the bank-masked move leaves "state before my run" in a log register that leaves as ONE 4-byte LDS
+//                      write per lane and group.  Per step: compare, conditional byte shift, mul_hi, shift, 24-bit
+//                      multiply, add - Encoding#RansEncPutSymbol with everything state-independent removed.
+// Slots and the chain wave meet through two counters per slot in LDS (batches staged / batches coded) instead of a
+// workgroup barrier: a slot whose block is being histogrammed, or has none left, simply feeds identity records.  The
+// staging area is four batches deep.  Order-1 tables live in LDS over the compacted alphabet (present symbols + 0) when
+// n*(n|1)*8 B fits the table region, else (same dense layout) in a per-slot global scratch.
 #include <climits>
 
 #include "internal.h"
@@ -45,11 +43,16 @@ constexpr int kGroups = 4;   // groups between two barriers (amortises the barri
 constexpr int kBatch = kGroup * kGroups;
 constexpr int kStageBufs = 4;  // batch i-1 is being turned into bytes, i runs, i+1 is prefetched, i+2 is being staged
 
-constexpr int kWgThreads = 128;   // chain wave + helper wave
+constexpr int kWgThreads = 128;   // the two waves of a slot
+constexpr int kSlots = 4;         // blocks in flight per workgroup, one per row of the chain wave
+// Twelve waves are launched and nine work.  The hardware places wave w of a workgroup on SIMD (w + k) mod 4 (measured:
+// scripts/ubench/hwid_bench.hip), so waves 0, 4 and 8 share a SIMD: wave 0 is the chain wave and waves 4 and 8 end at
+// once, which leaves the chain a SIMD of its own; the eight slot waves are 1-3, 5-7, 9 and 10 (wave 11 ends too).
+constexpr int kBlockThreads = 12 * 64;
 
 constexpr int kRingBytes = 4096;  // input ring of the helper wave: 4 x 1 KiB (order 1) or 1 x 4 KiB (order 0)
 
-// LDS of one workgroup, statically sized so that 4 workgroups fill the 160 KiB of a CU.
+// LDS of one slot, statically sized so that the four slots of a workgroup fill the 160 KiB of a CU.
 struct EncP2 {              // phase 2 (tables)
     uint32_t rowT[256];     // order-1 row totals (0 = context absent)
     uint32_t rowoff[256];   // serialised length of each row
@@ -59,7 +62,7 @@ struct alignas(16) EncP3 {  // phase 3 (coding loop)
     // [buffer][helper lane * 4 + k]: the record of step 4 * (lane >> 2) + k of the batch, state 3 - (lane & 3):
     // x_max-1, rcp_freq, bias, cmpl_freq | shift<<24 | small<<31.  A chain lane reads the four records of its run as 64 contiguous bytes.
     uint4 stage[kStageBufs][kBatch * 4];
-    uint32_t xs[2][64];        // [buffer][helper lane]: state before the first step of that lane's run
+    uint32_t xs[kStageBufs][64];  // [buffer][helper lane]: state before the first step of that lane's run
     uint8_t ring[kRingBytes];  // input bytes (dense symbol indices when the order-1 tables are in LDS)
     uint32_t gflag[kStageBufs];  // bit G: group G of the batch holds a symbol with freq < 16
     uint32_t fin[4];        // states after the last batch the chain ran
@@ -71,7 +74,19 @@ struct alignas(16) EncFixed {
     // block hand-over between the waves (written by the helper wave, read by both after a barrier)
     int32_t mode, stride, ent_off, tab_len, status;
     uint32_t ticket;
-    uint32_t pad[2];
+    uint32_t sync_cnt;    // arrivals at the slot's two-wave barrier
+    // hand-over between the slot's helper wave and the chain wave: absolute batch numbers of this slot since the launch
+    uint32_t staged;      // batches below this number are staged (written by the helper wave)
+    uint32_t done;        // batches below this number are coded and logged (written by the chain wave)
+    uint32_t emitted;     // batches below this number are turned into bytes: their staging buffers are free (helper wave)
+    uint32_t base;        // number of the current block's batch 0
+    uint32_t exitf;       // the slot has run out of blocks
+    uint32_t pad[4];
+    uint4 ident[4];       // identity records: what the chain wave's row reads while the slot has nothing staged
+    uint32_t hwid_chain;  // profiling build: HW_ID of the chain wave, batch-times this row stood still beside working rows
+    uint32_t idle_chain;
+    uint32_t pad2[2];
+    uint32_t sink[16];    // ... and where it writes meanwhile (p3 below is the slot's histogram space during phases 1 and 2)
     // The union comes last, directly in front of the table region: the part of the coding loop's buffers that phase 2
     // does not use (everything behind p2) is free during phases 1 and 2 and forms, together with the table region, one
     // contiguous "big" area for what only those phases need (pair counters, histogram words, staged rows).
@@ -90,12 +105,12 @@ struct alignas(16) EncLds : EncFixed {
 static_assert(sizeof(EncLds) == sizeof(EncFixed) + kTabBytes, "table region directly behind the coding-loop buffers");
 typedef EncLds EncFixedLds;  // phases 1 and 2 only touch the fixed part
 #ifdef HIP_SIM
-static EncLds lds;
+static EncLds lds4[kSlots];
 #else
-__shared__ EncLds lds;
+__shared__ EncLds lds4[kSlots];
 #endif
-// start of the big area (kBigBytes): behind p2, through the rest of p3 and the whole table region
-__device__ __forceinline__ uint8_t* lds_big() { return reinterpret_cast<uint8_t*>(&lds.p3) + sizeof(EncP2); }
+static_assert(sizeof(EncLds) * kSlots <= 160 * 1024, "four slots per CU");
+#define lds (lds4[slot_idx()])  // the slot of the calling wave (waves 2s and 2s+1)
 
 // A value that is the same in every lane of the wave, moved to a scalar register so that branches on it are scalar
 // branches: a wave then never walks a path of the other wave's role with an empty EXEC mask (where a barrier would
@@ -107,10 +122,78 @@ __device__ __forceinline__ uint8_t* lds_big() { return reinterpret_cast<uint8_t*
 #endif
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
-__device__ __forceinline__ int wave_id() { return UNIFORM(threadIdx.x >> 6); }
+__device__ __forceinline__ int phys_wave() { return UNIFORM(threadIdx.x >> 6); }
+__device__ __forceinline__ int worker_id() { return phys_wave() - 1 - (phys_wave() >> 2); }  // 1-3, 5-7, 9, 10 -> 0..7
+__device__ __forceinline__ int wave_id() { return worker_id() & 1; }   // within the slot: 0 aux, 1 helper
+__device__ __forceinline__ int slot_idx() { return (worker_id() >> 1) & 3; }
+__device__ __forceinline__ int stid() { return ((worker_id() & 1) << 6) | (int)(threadIdx.x & 63u); }  // thread of the slot
+// start of the big area (kBigBytes): behind p2, through the rest of p3 and the whole table region
+__device__ __forceinline__ uint8_t* lds_big() { return reinterpret_cast<uint8_t*>(&lds.p3) + sizeof(EncP2); }
 
-// Synchronisation among the lanes of ONE wave (phases 1 and 2 run in the helper wave alone while the chain wave
-// waits at the workgroup barrier): LDS operations of a wave execute in order, so only the compiler has to be held.
+// Hand-over words in LDS (read by one wave while another writes them).  On the GPU a plain LDS access between two
+// compiler barriers: the barrier in front makes the compiler load the word again, the one behind keeps what the word
+// announces from being read ahead of it (acquire) or written behind it (release); the LDS executes a wave's operations
+// in order and one 4-byte access is indivisible, so the hardware needs nothing.  (A volatile access would do, but it
+// compiles to a system-scope FLAT access with a full wait right behind it: a round trip on the chain wave's path.)
+// Atomics in the host harness.
+__device__ __forceinline__ uint32_t ld_flag(const uint32_t* p) {
+#ifdef HIP_SIM
+    return __atomic_load_n(p, __ATOMIC_ACQUIRE);
+#else
+    asm volatile("" ::: "memory");
+    const uint32_t v = *p;
+    asm volatile("" ::: "memory");
+    return v;
+#endif
+}
+__device__ __forceinline__ void st_flag(uint32_t* p, uint32_t v) {
+#ifdef HIP_SIM
+    __atomic_store_n(p, v, __ATOMIC_RELEASE);
+#else
+    asm volatile("" ::: "memory");
+    *p = v;
+    asm volatile("" ::: "memory");
+#endif
+}
+// the calling wave sleeps until *p has reached goal (a counter that only grows)
+__device__ __forceinline__ void wait_flag_ge(const uint32_t* p, uint32_t goal) {
+#ifdef HIP_SIM
+    if (lane_id() == 0)
+        while ((int32_t)(ld_flag(p) - goal) < 0) std::this_thread::yield();
+    __builtin_amdgcn_wave_barrier();
+#else
+    while ((int32_t)((uint32_t)UNIFORM(ld_flag(p)) - goal) < 0) __builtin_amdgcn_s_sleep(2);
+#endif
+}
+// Barrier between the two waves of a slot (the other slots and the chain wave go their own way, so the workgroup
+// barrier is not available): every wave adds one to a counter that only grows and waits for the next even value.
+// Memory operations issued before it have completed when it returns (the fences wait for both counters).
+__device__ __forceinline__ void slot_sync() {
+    uint32_t* cnt = &lds.sync_cnt;
+#ifdef HIP_SIM
+    __builtin_amdgcn_wave_barrier();
+    if (lane_id() == 0) {
+        const uint32_t t = __atomic_add_fetch(cnt, 1u, __ATOMIC_ACQ_REL);
+        const uint32_t goal = (t + 1u) & ~1u;
+        while ((int32_t)(ld_flag(cnt) - goal) < 0) std::this_thread::yield();
+    }
+    __builtin_amdgcn_wave_barrier();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    uint32_t t = 0;
+    if (lane_id() == 0) t = atomicAdd(cnt, 1u) + 1u;
+    const uint32_t goal = ((uint32_t)UNIFORM(t) + 1u) & ~1u;
+    for (int k = 0; (int32_t)((uint32_t)UNIFORM(ld_flag(cnt)) - goal) < 0; k++) {
+        if (k < 16)
+            __builtin_amdgcn_s_sleep(1);
+        else
+            __builtin_amdgcn_s_sleep(24);  // the aux wave waits out the whole coding loop here
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+}
+
+// Synchronisation among the lanes of ONE wave (phase 2 runs in the helper wave alone): LDS operations of a wave execute in order, so only the compiler has to be held.
 __device__ __forceinline__ void wave_sync() {
 #ifdef HIP_SIM
     __builtin_amdgcn_wave_barrier();
@@ -224,10 +307,10 @@ __device__ __forceinline__ void for_each_unit(const uint8_t* src, int32_t n16, i
 constexpr int kRep0 = 16, kRep0Stride = 257;
 static_assert(1024 + 2048 <= kTabBytes && kRep0 * kRep0Stride * 4 <= kBigBytes, "order-0 counts, symbols and replicas must fit");
 __device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* rep) {
-    const int l = (int)threadIdx.x;  // both waves
+    const int l = stid();  // both waves of the slot
     constexpr int R = kRep0;
     for (int i = l; i < R * kRep0Stride; i += kWgThreads) rep[i] = 0;
-    __syncthreads();
+    slot_sync();
     uint32_t* my = rep + (l & (R - 1)) * kRep0Stride;
     const int32_t n16 = n & ~15;
     for_each_unit<false>(src, n16, l, [&](const uint4& v, int32_t, uint32_t) {
@@ -241,13 +324,13 @@ __device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* 
         }
     });
     if (n16 + l < n) atomicAdd(&my[src[n16 + l]], 1u);
-    __syncthreads();
+    slot_sync();
     for (int j = l; j < 256; j += kWgThreads) {
         uint32_t s = 0;
         for (int r = 0; r < R; r++) s += rep[r * kRep0Stride + j];
         cnt[j] = s;
     }
-    __syncthreads();
+    slot_sync();
 }
 
 // order-1 pair counts: cnt[row(prev)*stride + col(cur)] with prev = 0 before the first byte
@@ -256,13 +339,13 @@ __device__ void hist_o0(const uint8_t* src, int32_t n, uint32_t* cnt, uint32_t* 
 // machine code the wide-alphabet path runs is then the code every small-alphabet block has already exercised.
 __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n, uint32_t* cnt, int stride, const uint8_t* dmap, uint32_t* rep,
                         int R, int rstride, int cells) {
-    const int l = (int)threadIdx.x;  // both waves; cnt has been zeroed (and that made visible) by the caller
+    const int l = stid();  // both waves of the slot; cnt has been zeroed (and that made visible) by the caller
     uint32_t* my = cnt;
     if (R > 1) {
         for (int i = l; i < R * rstride; i += kWgThreads) rep[i] = 0;
         my = rep + (l & (R - 1)) * rstride;
     }
-    __syncthreads();
+    slot_sync();
     const int32_t n16 = n & ~15;
     for_each_unit<true>(src, n16, l, [&](const uint4& v, int32_t, uint32_t prev) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -287,14 +370,14 @@ __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n,
             atomicAdd(&my[(uint32_t)dmap[c]], 1u);
         }
     }
-    __syncthreads();
+    slot_sync();
     if (R > 1) {
         for (int j = l; j < cells; j += kWgThreads) {
             uint32_t s = 0;
             for (int r = 0; r < R; r++) s += rep[r * rstride + j];
             cnt[j] += s;
         }
-        __syncthreads();
+        slot_sync();
     }
 }
 
@@ -304,10 +387,10 @@ __device__ __attribute__((noinline)) void hist_o1(const uint8_t* src, int32_t n,
 // global table cnt[cells].
 __device__ __attribute__((noinline)) void hist_o1_packed16(const uint8_t* src, int32_t n, uint32_t* cnt, int stride, const uint8_t* dmap,
                                                            uint32_t* w, int cells) {
-    const int l = (int)threadIdx.x;  // both waves
+    const int l = stid();  // both waves of the slot
     const int words = (cells + 1) >> 1;
     for (int i = l; i < words; i += kWgThreads) w[i] = 0;
-    __syncthreads();
+    slot_sync();
     auto bump = [&](uint32_t idx) { atomicAdd(&w[idx >> 1], 1u << (16u * (idx & 1u))); };
     const int32_t n16 = n & ~15;
     for_each_unit<true>(src, n16, l, [&](const uint4& v, int32_t, uint32_t prev) {
@@ -328,9 +411,9 @@ __device__ __attribute__((noinline)) void hist_o1_packed16(const uint8_t* src, i
         const int32_t q = n >> 2;
         for (int k = 1; k < 4; k++) bump((uint32_t)dmap[src[k * q]]);
     }
-    __syncthreads();
+    slot_sync();
     for (int i = l; i < cells; i += kWgThreads) cnt[i] = (w[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-    __syncthreads();
+    slot_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -661,17 +744,6 @@ enum { MODE_O0 = 0, MODE_O1_LDS = 1, MODE_O1_GLOBAL = 2 };
 constexpr int kGsEntOff = 264 * 1024;  // global scratch: packed symbols behind 256 x 257 counts
 static_assert(kGsEntOff >= 4 * 256 * 257 && kGsEntOff + 8 * 256 * 257 <= (int)ENC_GSCRATCH_BYTES, "global scratch layout");
 
-// Barrier between the two waves of the workgroup.  Only LDS traffic is exchanged across it, so it waits for the LDS
-// counter alone: __syncthreads() would also drain the helper wave's global loads and stores (a full memory round
-// trip per batch).
-__device__ __forceinline__ void pair_barrier() {
-#ifdef HIP_SIM
-    __syncthreads();
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
-
 // Input positions.  Step u of state j codes the byte at pos(u, j); positions fall by one per step inside a state's
 // stream (order 1: four quarters; order 0: one interleaved stream, four bytes per step).
 //   order 0 (E04 L12-57):  pos = (n & ~3) - 4u + j, step 0 is the n&3 tail (only states j < (n&3))
@@ -909,10 +981,10 @@ __device__ __forceinline__ uint32_t group_steps(uint32_t x, const uint4 (&P)[kRu
 #define QGROUP(STEP) QRUN(STEP, 0x1) QRUN(STEP, 0x2) QRUN(STEP, 0x4) QRUN(STEP, 0x8)
 // Both variants in ONE asm statement, the choice made by a scalar branch inside it (two statements under a C++ branch
 // leave the compiler free to keep the state in different registers on the two paths and to move registers at every join).
-// gs = the group's general flag, already in a scalar register.
-__device__ __forceinline__ uint32_t group_steps_both(uint32_t x, const uint4 (&P)[kRun], uint32_t gs, uint32_t& lg) {
+// gs = the ballot of the lanes whose batch flags the group as general: a scalar register pair by construction.
+__device__ __forceinline__ uint32_t group_steps_both(uint32_t x, const uint4 (&P)[kRun], unsigned long long gs, uint32_t& lg) {
     uint32_t t, r, m, p;
-    asm volatile("s_cmp_eq_u32 %[gs], 0\n\t"
+    asm volatile("s_cmp_eq_u64 %[gs], 0\n\t"
                  "s_cbranch_scc1 .LgrpF_%=\n\t" QGROUP(QSTEP_G) "s_branch .LgrpD_%=\n"
                  ".LgrpF_%=:\n\t" QGROUP(QSTEP) ".LgrpD_%=:\n\t"
                  : [x] "+v"(x), [lg] "+v"(lg), [t] "=&v"(t), [r] "=&v"(r), [m] "=&v"(m), [p] "=&v"(p)
@@ -924,13 +996,14 @@ __device__ __forceinline__ uint32_t group_steps_both(uint32_t x, const uint4 (&P
 }
 #endif
 
-// Collective over both waves.  Returns (in the helper wave) the payload length including the 16 state bytes, or a
-// negative code.  The payload is written downwards from pend.
-// Iteration i: the chain wave runs batch i (records of group G+1 are fetched while group G runs) and logs into xs[i&1];
-// the helper wave turns the log of batch i-1 into bytes (re-reading that batch's records from the staging area),
-// expands the symbols of batch i+2 into stage[(i+2)&3] and looks up the symbols of batch i+3; one barrier.  Input
-// reaches the helper through an LDS ring that is refilled with 16-byte loads a whole chunk (4 batches) before it is
-// needed, so that no iteration waits for global memory.
+// Phase 3 of a slot, both of its waves.  The aux wave STAGES: it fetches the symbol / context bytes (through an LDS
+// ring refilled with 16-byte loads a whole chunk of 4 batches before it is needed, so that no batch waits for global
+// memory), looks the symbols up, expands them into the staging area and publishes the batch to the chain wave.  The
+// helper wave EMITS: once the chain wave has coded a batch it turns the logged states into bytes (re-reading the batch's
+// records from the staging area), written downwards from pend, and releases the batch's staging buffer.  Batches carry
+// absolute numbers (base + b) that index the four staging / log buffers, so that the chain wave needs no notion of
+// blocks: it codes whatever is staged.  Returns (helper wave) the payload length including the 16 state bytes, or a
+// negative code; the aux wave returns 0.
 // In-kernel cycle stamps exist only in the profiling build (make prof -> libcramgpu_prof.so): s_memtime shares the
 // LDS counter and, being out of order, makes the compiler wait for ALL outstanding LDS reads at every use.
 #ifdef CRAMGPU_PROF_BUILD
@@ -945,162 +1018,121 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
     EncLds* L = &lds;
     const int32_t n = UNIFORM(n_), stride = UNIFORM(stride_), room = UNIFORM(room_);  // arrive in vector registers
     const int l = lane_id();
-    const bool helper = wave_id() == 1;
-    const int js = l & 3, j = 3 - js;        // helper lane -> state: lane order = emission order within a step
-    const int cl = l & 15;                   // chain lane within its row (the four rows do the same work)
+    const int js = l & 3, j = 3 - js;        // lane -> state: lane order = emission order within a step
     Geo g;
     g.n = n;
     g.q = n >> 2;
     g.rem = MODE == MODE_O0 ? 0 : n - 4 * g.q;
     g.U = MODE == MODE_O0 ? g.q + 1 : g.q + g.rem;
     const int32_t nbatch = (g.U + kBatch - 1) / kBatch;
-    const int32_t limit = room - 16;
-    const uint4 ident = make_uint4(0x7FFFFFFFu, 0u, 0u, 0u);  // identity step for inactive (step, state) pairs (x < 2^31)
-    uint32_t x = RANS_BYTE_L;  // chain wave: the states, on their way round the row
-    uint32_t lg = 0;
-    uint2 e2[kRun];     // helper wave: looked-up symbols of batch i+3
-    bool act2[kRun];
+    const uint32_t base = (uint32_t)UNIFORM(L->base);
+    if (wave_id() == 0) {
+        // ---------------- the stager
+        const uint4 ident = make_uint4(0x7FFFFFFFu, 0u, 0u, 0u);  // identity step for inactive (step, state) pairs (x < 2^31)
+        uint2 e2[kRun];     // looked-up symbols of the next batch
+        bool act2[kRun];
+        Cursor cur = cursor_init<MODE>(g, kRun * (l >> 2), j);
+        ChunkRegs CR;
+        // expand the looked-up run into the staging buffer of batch b (relative number), general flags of its four
+        // groups (bit 4: the chain wave starts a new block with this batch), and let the chain wave have the batch
+        auto stage_run = [&](int32_t b) {
+            const int sb = (int)((base + (uint32_t)b) & (kStageBufs - 1));
+            uint32_t any = 0;
 #pragma unroll
-    for (int k = 0; k < kRun; k++) e2[k] = make_uint2(0u, 0u), act2[k] = false;
-    Cursor cur = cursor_init<MODE>(g, kRun * (l >> 2), j);
-    const uint32_t m1 = js >= 1 ? ~0u : 0u, m2 = js >= 2 ? ~0u : 0u;
-    ChunkRegs CR;
-    int32_t run = 0;
-    bool failed = false;
-    // expand the looked-up run into the staging buffer sb, general flags of its four groups
-    auto stage_run = [&](int sb) {
-        uint32_t any = 0;
-#pragma unroll
-        for (int k = 0; k < kRun; k++) {
-            const uint4 A = act2[k] ? expand_symbol(e2[k]) : ident;
-            L->p3.stage[sb][l * kRun + k] = A;
-            any |= A.w;
-        }
-        const unsigned long long sm = __ballot((int32_t)any < 0);
-        if (l == 0)
-            L->p3.gflag[sb] = ((sm & 0xFFFFull) ? 1u : 0u) | ((sm & 0xFFFF0000ull) ? 2u : 0u) | ((sm & 0xFFFF00000000ull) ? 4u : 0u) |
-                              ((sm >> 48) ? 8u : 0u);
-    };
-    if (helper) {
+            for (int k = 0; k < kRun; k++) {
+                const uint4 A = act2[k] ? expand_symbol(e2[k]) : ident;
+                L->p3.stage[sb][l * kRun + k] = A;
+                any |= A.w;
+            }
+            const unsigned long long sm = __ballot((int32_t)any < 0);
+            if (l == 0)
+                L->p3.gflag[sb] = ((sm & 0xFFFFull) ? 1u : 0u) | ((sm & 0xFFFF0000ull) ? 2u : 0u) | ((sm & 0xFFFF00000000ull) ? 4u : 0u) |
+                                  ((sm >> 48) ? 8u : 0u) | (b == 0 ? 16u : 0u);
+            WSYNC();
+            if (l == 0) st_flag(&L->staged, base + (uint32_t)b + 1u);
+        };
         chunk_load<MODE>(src, g, 0, l, CR);
         chunk_store<MODE>(CR, L->p3.ring, L->dmap);
         chunk_load<MODE>(src, g, 1, l, CR);
         WSYNC();
-#pragma unroll
-        for (int b0 = 0; b0 < 2; b0++) {  // batches 0 and 1
-            lookup_run<MODE>(cur, L->p3.ring, ent, stride, e2, act2);
-            cursor_next<MODE>(cur);
-            stage_run(b0);
-        }
         lookup_run<MODE>(cur, L->p3.ring, ent, stride, e2, act2);
         cursor_next<MODE>(cur);
-    }
-    pair_barrier();
-#ifndef HIP_SIM
-    if (!helper) __builtin_amdgcn_s_setprio(3);  // the chain wave is the critical path of the block
-#endif
-    // chain wave: records of the group about to run, flags of the batch about to run
-    uint4 Pc[kRun];
-    uint32_t fc = 0;
-    if (!helper) {
-        fc = L->p3.gflag[0];
-#pragma unroll
-        for (int k = 0; k < kRun; k++) Pc[k] = L->p3.stage[0][cl * kRun + k];
-    }
-    unsigned long long busy = 0;
-    for (int32_t i = 0; i <= nbatch; i++) {
-        const int sb = i & (kStageBufs - 1), sb1 = (i + 1) & (kStageBufs - 1), sb2 = (i + 2) & (kStageBufs - 1);
-        const long long tb = prof ? clock64() : 0;
-        if (!helper) {
-            if (i < nbatch) {
-                const uint32_t fn = L->p3.gflag[sb1];  // the next batch's flags land while this one runs
-                const uint32_t gsb = (uint32_t)UNIFORM(fc);
-#pragma unroll
-                for (int G = 0; G < kGroups; G++) {
-                    // records of the next group (the first one of batch i+1 behind the last one of batch i)
-                    uint4 Pn[kRun];
-                    const uint4* nx = G + 1 < kGroups ? &L->p3.stage[sb][(kGroup * (G + 1) + cl) * kRun] : &L->p3.stage[sb1][cl * kRun];
-#pragma unroll
-                    for (int k = 0; k < kRun; k++) Pn[k] = nx[k];
-#ifdef HIP_SIM
-                    x = ((gsb >> G) & 1u) ? group_steps<true>(x, Pc, lg) : group_steps<false>(x, Pc, lg);
-#else
-                    x = group_steps_both(x, Pc, (gsb >> G) & 1u, lg);
-#endif
-                    L->p3.xs[i & 1][kGroup * G + cl] = lg;
-#pragma unroll
-                    for (int k = 0; k < kRun; k++) Pc[k] = Pn[k];
-                }
-                if (cl >= 12) L->p3.fin[3 - (cl & 3)] = x;  // bank 3 holds the states after a group
-                fc = fn;
-            }
-        } else {
-            // bytes of batch i-1 in the reference's emission order: step, then state 3,2,1,0 = run, step of the run, lane & 3
-            if (i > 0) {
-                uint32_t xv = L->p3.xs[(i - 1) & 1][l];
-                uint4 R[kRun];
-#pragma unroll
-                for (int k = 0; k < kRun; k++) R[k] = L->p3.stage[(i - 1) & (kStageBufs - 1)][l * kRun + k];
-                uint32_t lo16[kRun], nbp = 0;  // byte counts of the four steps, one per byte of nbp
-#pragma unroll
-                for (int k = 0; k < kRun; k++) {
-                    uint32_t nb;
-                    lo16[k] = xv;
-                    xv = put_symbol(xv, R[k], nb);
-                    nbp |= nb << (8 * k);
-                }
-                // positions: runs in lane order; inside a run step by step, inside a step the quad's lanes in order
-                uint32_t S = nbp;  // inclusive scan over the quad, all four steps at once (a count is at most 2)
-                S += dpp0<0x90>(S) & m1;   // quad_perm:[0,0,1,2]
-                S += dpp0<0x44>(S) & m2;   // quad_perm:[0,1,0,1]
-                const uint32_t Qp = dpp0<0xFF>(S);  // quad totals per step
-                const uint32_t Bp = S - nbp;        // bytes of the lower lanes of the quad per step
-                const uint32_t I = wave_incl_scan((nbp * 0x01010101u) >> 24);
-                const int32_t tot = (int32_t)lane63(I);
-                uint32_t acc = (uint32_t)run + dpp0<0xFF>(I) - ((Qp * 0x01010101u) >> 24);  // bytes in front of the quad's run
-                if (run + tot > limit) failed = true;
-                if (!failed) {
-#pragma unroll
-                    for (int k = 0; k < kRun; k++) {
-                        const uint32_t nb = (nbp >> (8 * k)) & 0xFFu;
-                        const int32_t idx = (int32_t)(acc + ((Bp >> (8 * k)) & 0xFFu));
-                        if (nb >= 1) pend[-1 - idx] = (uint8_t)lo16[k];
-                        if (nb == 2) pend[-2 - idx] = (uint8_t)(lo16[k] >> 8);
-                        acc += (Qp >> (8 * k)) & 0xFFu;
-                    }
-                    run += tot;
-                }
-            }
-            // batch i+2: expand the symbols looked up one iteration ago
-            stage_run(sb2);
-            // input ring: chunk c (kChunkBatches batches) is needed from iteration c * kChunkBatches - 3 on (the lookup
-            // of batch i + 3 below); it is written at (c - 1) * kChunkBatches from the registers that were loaded one
-            // chunk of iterations earlier, and the next chunk's loads are issued
-            if ((i & (kChunkBatches - 1)) == 0) {
+        for (int32_t b = 0; b < nbatch; b++) {
+            // the buffer held batch b - 4: coded, and turned into bytes by the helper wave
+            wait_flag_ge(&L->emitted, base + (uint32_t)b - (uint32_t)(kStageBufs - 1));
+            stage_run(b);
+            // input ring: chunk c (kChunkBatches batches) is needed by the lookup of its first batch, which happens one
+            // batch earlier; it is written another two batches earlier from the registers that were loaded a chunk of
+            // batches before that, and the next chunk's loads are issued
+            if (((b - 2) & (kChunkBatches - 1)) == 0 && b >= 2) {
                 chunk_store<MODE>(CR, L->p3.ring, L->dmap);
-                chunk_load<MODE>(src, g, i / kChunkBatches + 2, l, CR);
+                chunk_load<MODE>(src, g, (b - 2) / kChunkBatches + 2, l, CR);
                 WSYNC();
             }
-            // batch i+3: symbol lookup (the table reads land while this wave is at the barrier)
-            lookup_run<MODE>(cur, L->p3.ring, ent, stride, e2, act2);
+            lookup_run<MODE>(cur, L->p3.ring, ent, stride, e2, act2);  // batch b + 1 (the table reads land while this wave waits)
             cursor_next<MODE>(cur);
         }
-        if (prof) busy += (unsigned long long)(clock64() - tb);
-        pair_barrier();
+        return 0;
     }
-#ifndef HIP_SIM
-    if (!helper) __builtin_amdgcn_s_setprio(0);
-#endif
-    if (prof) {
-        if (!helper && l == 0) L->p3.cbusy = busy;
-        pair_barrier();
-        if (helper && l == 0) {
-            prof[2] = busy;
-            prof[3] = L->p3.cbusy;
-            prof[4] = (unsigned long long)nbatch;
+    // ---------------- the emitter
+    const int32_t limit = room - 16;
+    const uint32_t m1 = js >= 1 ? ~0u : 0u, m2 = js >= 2 ? ~0u : 0u;
+    int32_t run = 0;
+    bool failed = false;
+    unsigned long long busy = 0;
+    for (int32_t b = 0; b < nbatch; b++) {
+        // bytes of batch b in the reference's emission order: step, then state 3,2,1,0 = run, step of the run, lane & 3
+        wait_flag_ge(&L->done, base + (uint32_t)b + 1u);  // the chain wave has logged the batch
+        const long long tb = prof ? clock64() : 0;
+        const int eb = (int)((base + (uint32_t)b) & (kStageBufs - 1));
+        uint32_t xv = L->p3.xs[eb][l];
+        uint4 R[kRun];
+#pragma unroll
+        for (int k = 0; k < kRun; k++) R[k] = L->p3.stage[eb][l * kRun + k];
+        uint32_t lo16[kRun], nbp = 0;  // byte counts of the four steps, one per byte of nbp
+#pragma unroll
+        for (int k = 0; k < kRun; k++) {
+            uint32_t nb;
+            lo16[k] = xv;
+            xv = put_symbol(xv, R[k], nb);
+            nbp |= nb << (8 * k);
         }
+        WSYNC();
+        if (l == 0) st_flag(&L->emitted, base + (uint32_t)b + 1u);  // log and records are in registers: the buffer is free
+        // positions: runs in lane order; inside a run step by step, inside a step the quad's lanes in order
+        uint32_t S = nbp;  // inclusive scan over the quad, all four steps at once (a count is at most 2)
+        S += dpp0<0x90>(S) & m1;   // quad_perm:[0,0,1,2]
+        S += dpp0<0x44>(S) & m2;   // quad_perm:[0,1,0,1]
+        const uint32_t Qp = dpp0<0xFF>(S);  // quad totals per step
+        const uint32_t Bp = S - nbp;        // bytes of the lower lanes of the quad per step
+        const uint32_t I = wave_incl_scan((nbp * 0x01010101u) >> 24);
+        const int32_t tot = (int32_t)lane63(I);
+        uint32_t acc = (uint32_t)run + dpp0<0xFF>(I) - ((Qp * 0x01010101u) >> 24);  // bytes in front of the quad's run
+        if (run + tot > limit) failed = true;
+        if (!failed) {
+#pragma unroll
+            for (int k = 0; k < kRun; k++) {
+                const uint32_t nb = (nbp >> (8 * k)) & 0xFFu;
+                const int32_t idx = (int32_t)(acc + ((Bp >> (8 * k)) & 0xFFu));
+                if (nb >= 1) pend[-1 - idx] = (uint8_t)lo16[k];
+                if (nb == 2) pend[-2 - idx] = (uint8_t)(lo16[k] >> 8);
+                acc += (Qp >> (8 * k)) & 0xFFu;
+            }
+            run += tot;
+        }
+        if (prof) busy += (unsigned long long)(clock64() - tb);
     }
-    if (!helper) return 0;
+    // the chain wave has coded all nbatch batches: the next block's batches follow on
+    if (l == 0) L->base = base + (uint32_t)nbatch;
+    if (prof && l == 0) {
+        prof[2] = busy;
+        prof[4] = (unsigned long long)nbatch;
+#ifdef CRAMGPU_PROF_BUILD
+        prof[3] = ((unsigned long long)L->hwid_chain << 32) | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+        prof[5] = L->idle_chain;
+        L->idle_chain = 0;
+#endif
+    }
     if (failed) return CRAMGPU_E_INSUFFICIENT;
     // E04 L49-53 / E14 L78-82: big-endian rans3..rans0, then Utils#reverse => stream starts LE rans0..rans3
     if (l < 4) {
@@ -1111,7 +1143,130 @@ __device__ int32_t encode_stream(const uint8_t* src, int32_t n_, const uint2* en
         p[2] = (uint8_t)(xf >> 16);
         p[3] = (uint8_t)(xf >> 24);
     }
+    WSYNC();
     return run + 16;
+}
+
+// The chain wave: row s (lanes 16s .. 16s+15) codes whatever slot s has staged, batch by batch, and never waits for a
+// slot: a row whose slot has nothing staged reads identity records (its states stand still) while the other rows go on.
+// It ends when every slot has run out of blocks.
+__device__ void chain_loop() {
+    const int l = lane_id();
+    const int cl = l & 15;
+    EncLds* S = &lds4[l >> 4];
+    uint32_t x = RANS_BYTE_L, lg = 0;
+    uint32_t c = 0;  // batches of my slot coded so far
+#ifndef HIP_SIM
+    __builtin_amdgcn_s_setprio(3);  // the chain is the critical path of all four blocks
+#endif
+#ifdef CRAMGPU_PROF_BUILD
+    if (cl == 0) S->hwid_chain = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+#endif
+    // what the next batch-time needs is fetched during the current one: the slot's staged counter during group 1, the
+    // flags and the first group's records during group 2 (addresses depend on the counter), so that no batch begins by
+    // waiting for LDS.  A row whose slot had nothing staged at that moment stands still for one batch-time.
+    auto row_view = [&](uint32_t st) {
+#ifdef HIP_SIM
+        st = __shfl(st, l & 48);  // the harness's lanes read at different times: the row takes its first lane's view
+#endif
+        return st;
+    };
+    uint32_t st = row_view(ld_flag(&S->staged));
+    bool act = (int32_t)(st - c) > 0, was = false;
+    int buf = (int)(c & (kStageBufs - 1));
+    uint32_t f = act ? S->p3.gflag[buf] : 0u;
+    const uint4* rec = act ? &S->p3.stage[buf][cl * kRun] : &S->ident[0];
+    uint4 Pc[kRun];
+#pragma unroll
+    for (int k = 0; k < kRun; k++) Pc[k] = rec[k];
+    for (;;) {
+        if (__ballot(act) == 0) {  // nothing staged anywhere: poll
+            const bool gone = ld_flag(&S->exitf) != 0;
+            st = row_view(ld_flag(&S->staged));
+            act = (int32_t)(st - c) > 0;
+            if (__ballot(!gone || act) == 0) break;  // every slot has run out of blocks
+            if (__ballot(act) == 0) {
+#ifdef HIP_SIM
+                std::this_thread::yield();
+#else
+                __builtin_amdgcn_s_sleep(4);
+#endif
+                continue;
+            }
+            f = act ? S->p3.gflag[buf] : 0u;
+            rec = act ? &S->p3.stage[buf][cl * kRun] : &S->ident[0];
+#pragma unroll
+            for (int k = 0; k < kRun; k++) Pc[k] = rec[k];
+        }
+        // a row that has just run dry looks once more (its helper may have been a moment late: without this the row would
+        // stand still for a whole batch-time); rows that are dry for longer (histogram phases) do not hold the others up
+        if (__ballot(!act && was) != 0) {
+            st = row_view(ld_flag(&S->staged));
+            const bool now = !act && was && (int32_t)(st - c) > 0;
+            if (now) {
+                act = true;
+                f = S->p3.gflag[buf];
+                rec = &S->p3.stage[buf][cl * kRun];
+#pragma unroll
+                for (int k = 0; k < kRun; k++) Pc[k] = rec[k];
+            }
+        }
+        was = act;
+#ifdef CRAMGPU_PROF_BUILD
+        if (!act && cl == 0) S->idle_chain = S->idle_chain + 1;
+#endif
+        if (f & 16u) x = RANS_BYTE_L;  // the batch opens a block
+        // a group takes the general variant when any row's batch flags it: the ballot is the scalar the branch tests
+        unsigned long long gs[kGroups];
+#pragma unroll
+        for (int G = 0; G < kGroups; G++) gs[G] = __ballot(((f >> G) & 1u) != 0);
+        // the run's four records: 64 contiguous bytes per lane, groups 16 lanes apart; an idle row reads the identity
+        // and writes into the sink (p3 is its slot's histogram space during phases 1 and 2)
+        const int gstep = act ? kGroup * kRun : 0;
+        uint32_t* logp = act ? &S->p3.xs[buf][cl] : &S->sink[cl];
+        const int lstep = act ? kGroup : 0;
+        uint32_t st2 = 0, f2 = 0;
+        bool act2 = false;
+        int buf2 = 0;
+        const uint4* rec2 = rec;
+#pragma unroll
+        for (int G = 0; G < kGroups; G++) {
+            uint4 Pn[kRun];  // records of the next group land while this one runs
+            if (G + 1 < kGroups) {
+#pragma unroll
+                for (int k = 0; k < kRun; k++) Pn[k] = rec[gstep * (G + 1) + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < kRun; k++) Pn[k] = rec2[k];
+            }
+#ifdef HIP_SIM
+            x = gs[G] ? group_steps<true>(x, Pc, lg) : group_steps<false>(x, Pc, lg);
+#else
+            x = group_steps_both(x, Pc, gs[G], lg);
+#endif
+            logp[lstep * G] = lg;
+            if (G == 1) st2 = row_view(ld_flag(&S->staged));
+            if (G == 2) {
+                const uint32_t c2 = c + (act ? 1u : 0u);
+                act2 = (int32_t)(st2 - c2) > 0;
+                buf2 = (int)(c2 & (kStageBufs - 1));
+                f2 = act2 ? S->p3.gflag[buf2] : 0u;
+                rec2 = act2 ? &S->p3.stage[buf2][cl * kRun] : &S->ident[0];
+            }
+#pragma unroll
+            for (int k = 0; k < kRun; k++) Pc[k] = Pn[k];
+        }
+        if (cl >= 12) *(act ? &S->p3.fin[3 - (cl & 3)] : &S->sink[cl]) = x;  // bank 3 holds the states after a group
+        c += act ? 1u : 0u;
+#ifdef HIP_SIM
+        __builtin_amdgcn_wave_barrier();
+#endif
+        st_flag(&S->done, c);
+        st = st2, act = act2, buf = buf2, f = f2, rec = rec2;
+    }
+#ifndef HIP_SIM
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // Each mode's coding loop is a non-inlined function so that it gets its own register allocation.
@@ -1193,7 +1348,7 @@ __device__ __attribute__((noinline)) Prep prep_o1(Blk B) {
             }
         }
     }
-    __syncthreads();  // maps written, cnt0 read by both waves: the table region can be reused
+    slot_sync();  // maps written, cnt0 read by both waves: the table region can be reused
     const int ns = (int)nsym;
     const int stride = ns | 1;
     const int cells = ns * stride;
@@ -1222,12 +1377,12 @@ __device__ __attribute__((noinline)) Prep prep_o1(Blk B) {
     if (packed) {
         hist_o1_packed16(B.src, B.n, cnt, stride, L->dmap, reinterpret_cast<uint32_t*>(big), cells);
     } else {
-        for (int i = (int)threadIdx.x; i < cells; i += kWgThreads) cnt[i] = 0;
+        for (int i = stid(); i < cells; i += kWgThreads) cnt[i] = 0;
         if (!in_lds) __threadfence();  // the scratch was another block's a moment ago: write back / invalidate around each phase
         hist_o1(B.src, B.n, cnt, stride, L->dmap, rep, R, rstride, cells);  // begins with a workgroup barrier
     }
     if (!in_lds) __threadfence();
-    __syncthreads();
+    slot_sync();
     if (!helper) return r;
     if (in_lds) {
         r.tab_len = tables_o1(cnt, ent, ns, ns, stride, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);
@@ -1270,7 +1425,7 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
         uint8_t* pend = slot + cap;
         Blk B{a.in + d.in_off, slot, gs, a.rcp_tab, a.prof ? a.prof + 8 * (size_t)b : nullptr, n, cap};
         const long long t0 = PROF_ON(a.prof) ? clock64() : 0;
-        {  // phases 1 and 2: both waves count, the helper wave builds the tables while the chain wave waits below
+        {  // phases 1 and 2: both waves of the slot count, the helper wave builds the tables
             Prep p;
             if (order == 0) {
                 p = prep_o0(B);
@@ -1285,11 +1440,14 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
                 L->status = p.status;
             }
         }
-        __syncthreads();
+        slot_sync();
         const int32_t mode = UNIFORM(L->mode), stride = UNIFORM(L->stride), ent_off = UNIFORM(L->ent_off),
                       tab_len = UNIFORM(L->tab_len);
         int32_t pay_len = UNIFORM(L->status);
         const long long t1 = PROF_ON(a.prof) ? clock64() : 0;
+#ifdef CRAMGPU_PROF_BUILD
+        const long long w1 = PROF_ON(a.prof) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;  // constant 100 MHz
+#endif
         if (pay_len == 0) {
             if (mode == MODE_O0)
                 pay_len = stream_o0(B, tab_len);
@@ -1302,6 +1460,10 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
         if (PROF_ON(a.prof) && l == 0) {
             B.prof[0] = (unsigned long long)(t1 - t0);
             B.prof[1] = (unsigned long long)(clock64() - t1);
+#ifdef CRAMGPU_PROF_BUILD
+            B.prof[6] = (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - w1);  // phase 3 in 10 ns units
+            B.prof[7] = (unsigned long long)__builtin_amdgcn_s_memrealtime();                    // end of the block
+#endif
         }
         if (pay_len < 0) {
             result = pay_len;
@@ -1336,17 +1498,40 @@ __device__ void encode_block(const RansArgs& a, int b, uint8_t* gs) {
     }
 }
 
-__global__ __launch_bounds__(128) void rans_encode_kernel(RansArgs a) {
+__global__ __launch_bounds__(kBlockThreads) void rans_encode_kernel(RansArgs a) {
+    const int pw = phys_wave();
+    const bool chain = pw == 0, spare = pw == 4 || pw == 8 || pw == 11;
+    if (!chain && !spare) {  // the slot's hand-over words and identity records, before anybody looks at them
+        EncFixedLds* L = &lds;
+        const int t = stid();
+        if (t == 64) {
+            L->sync_cnt = 0;
+            L->staged = 0;
+            L->done = 0;
+            L->emitted = 0;
+            L->base = 0;
+            L->exitf = 0;
+            L->idle_chain = 0;
+        }
+        if (t >= 64 && t < 68) L->ident[t - 64] = make_uint4(0x7FFFFFFFu, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    if (spare) return;
+    if (chain) {
+        chain_loop();
+        return;
+    }
     EncFixedLds* L = &lds;
-    uint8_t* gs = a.gscratch + (size_t)blockIdx.x * ENC_GSCRATCH_BYTES;
+    uint8_t* gs = a.gscratch + ((size_t)blockIdx.x * kSlots + (size_t)slot_idx()) * ENC_GSCRATCH_BYTES;
     for (;;) {
-        if (threadIdx.x == 64) L->ticket = atomicAdd(a.ticket, 1u);
-        __syncthreads();
+        if (stid() == 64) L->ticket = atomicAdd(a.ticket, 1u);
+        slot_sync();
         const uint32_t t = (uint32_t)UNIFORM(L->ticket);
-        __syncthreads();  // both waves hold the ticket before the helper can draw the next one
-        if (t >= (uint32_t)a.n_blocks) break;  // every workgroup reaches this: the queue only grows
+        slot_sync();  // both waves hold the ticket before the helper can draw the next one
+        if (t >= (uint32_t)a.n_blocks) break;  // every slot reaches this: the queue only grows
         encode_block(a, a.perm ? a.perm[t] : (int)t, gs);  // no permutation: blocks in table order
     }
+    if (stid() == 64) st_flag(&L->exitf, 1u);
 }
 
 // Encoding#RansEncSymbolInit L31-36: rcp_freq = (int)(((1L << (shift + 31)) + freq - 1) / freq) for freq >= 2
@@ -1368,7 +1553,8 @@ size_t rans_encode_fixed_lds() { return 0; }  // the encoder's LDS is static
 
 hipError_t launch_rans_encode(const RansArgs& a, int n_groups, size_t lds_bytes, hipStream_t s) {
     (void)lds_bytes;
-    hipLaunchKernelGGL(rans_encode_kernel, dim3(n_groups), dim3(128), 0, s, a);
+    // n_groups = slots (blocks in flight) the caller sized the global scratch for, four to a workgroup
+    hipLaunchKernelGGL(rans_encode_kernel, dim3((n_groups + kSlots - 1) / kSlots), dim3(kBlockThreads), 0, s, a);
     return hipGetLastError();
 }
 
