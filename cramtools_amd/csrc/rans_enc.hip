@@ -1316,6 +1316,11 @@ __device__ __attribute__((noinline)) Prep prep_o0(Blk B) {
 
 // Order 1: packed symbols over the dense alphabet in the LDS table region and pair counts in the spare area when they
 // fit, else both in the workgroup's global scratch (same layout, same code: hist_o1 / tables_o1 take generic pointers).
+// The alphabet of a long block is taken from its first kSampleBytes: the pair counts only need to know which symbols
+// occur (the order-0 counts themselves are not part of an order-1 stream), so the order-0 pass over the whole block -
+// a third of the input traffic and 40 % of phase 1 - shrinks to a sample.  Symbols the sample did not see count into an
+// overflow row / column of the pair table; if anything landed there the block is counted again with its full alphabet.
+constexpr int32_t kSampleBytes = 64 * 1024;
 __device__ __attribute__((noinline)) Prep prep_o1(Blk B) {
     const int l = lane_id();
     const bool helper = wave_id() == 1;
@@ -1323,66 +1328,86 @@ __device__ __attribute__((noinline)) Prep prep_o1(Blk B) {
     uint8_t* tab = lds.tab;
     uint32_t* cnt0 = reinterpret_cast<uint32_t*>(tab);
     uint32_t* rep0 = reinterpret_cast<uint32_t*>(lds_big());
-    hist_o0(B.src, B.n, cnt0, rep0);
-    // dense alphabet = present symbols plus 0 (context 0 always exists); both waves derive its size, one writes the maps
-    uint32_t present = 0, mine = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int jj = l * 4 + k;
-        bool p = cnt0[jj] != 0 || jj == 0;
-        present |= (p ? 1u : 0u) << k;
-        mine += p ? 1u : 0u;
-    }
-    uint32_t nsym;
-    uint32_t di = wave_excl_scan(mine, nsym);
-    if (helper) {
+    uint8_t* big = lds_big();
+    Prep r{MODE_O1_LDS, 0, 0, 0, 0};
+    uint32_t* cnt;
+    uint2* ent;
+    int ns, stride;
+    bool in_lds;
+    for (int attempt = B.n > kSampleBytes ? 0 : 1;; attempt++) {
+        hist_o0(B.src, attempt == 0 ? kSampleBytes : B.n, cnt0, rep0);
+        // dense alphabet = present symbols plus 0 (context 0 always exists); both waves derive its size, one writes the maps
+        uint32_t present = 0, mine = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             int jj = l * 4 + k;
-            if (present & (1u << k)) {
-                L->dmap[jj] = (uint8_t)di;
-                L->syml[di] = (uint8_t)jj;
-                di++;
-            } else {
-                L->dmap[jj] = 0;
-            }
+            bool p = cnt0[jj] != 0 || jj == 0;
+            present |= (p ? 1u : 0u) << k;
+            mine += p ? 1u : 0u;
         }
+        uint32_t nsym;
+        uint32_t di = wave_excl_scan(mine, nsym);
+        const bool ovf = attempt == 0 && nsym < 256;  // a sample that holds all 256 values has nothing left to miss
+        if (helper) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int jj = l * 4 + k;
+                if (present & (1u << k)) {
+                    L->dmap[jj] = (uint8_t)di;
+                    L->syml[di] = (uint8_t)jj;
+                    di++;
+                } else {
+                    L->dmap[jj] = ovf ? (uint8_t)nsym : 0;
+                }
+            }
+            if (ovf && l == 0) L->syml[nsym] = 0;  // never serialised: its counts are zero or the block is counted again
+        }
+        slot_sync();  // maps written, cnt0 read by both waves: the table region can be reused
+        ns = (int)nsym + (ovf ? 1 : 0);
+        stride = ns | 1;
+        const int cells = ns * stride;
+        // in LDS: packed symbols (8 B per cell, needed by the coding loop) in the table region, pair counts (4 B per cell,
+        // dead once the symbols exist) in the spare area
+        in_lds = 8 * cells + 16 <= kTabBytes && 4 * cells + 16 <= kSpareBytes;
+        r.mode = in_lds ? MODE_O1_LDS : MODE_O1_GLOBAL;
+        r.stride = stride;
+        uint32_t* rep = nullptr;
+        int R = 1;
+        const int rstride = cells | 1;
+        if (in_lds) {
+            cnt = reinterpret_cast<uint32_t*>(big);
+            ent = reinterpret_cast<uint2*>(tab);
+            const int rep_off = (8 * cells + 15) & ~15;
+            while (R < 32 && rep_off + 2 * R * rstride * 4 <= kTabBytes) R <<= 1;
+            rep = reinterpret_cast<uint32_t*>(tab + rep_off);
+            r.ent_off = 0;
+        } else {
+            cnt = reinterpret_cast<uint32_t*>(B.gs);
+            ent = reinterpret_cast<uint2*>(B.gs + kGsEntOff);
+        }
+        const bool packed = !in_lds && B.n < 65536 && 2 * cells + 8 <= kBigBytes;
+        if (packed) {
+            hist_o1_packed16(B.src, B.n, cnt, stride, L->dmap, reinterpret_cast<uint32_t*>(big), cells);
+        } else {
+            for (int i = stid(); i < cells; i += kWgThreads) cnt[i] = 0;
+            if (!in_lds) __threadfence();  // the scratch was another block's a moment ago: write back / invalidate around each phase
+            hist_o1(B.src, B.n, cnt, stride, L->dmap, rep, R, rstride, cells);  // begins with a slot barrier
+        }
+        if (!in_lds) __threadfence();
+        slot_sync();
+        if (!ovf) break;
+        // did a symbol outside the sample's alphabet turn up?  (its row and its column of the pair table)
+        if (helper) {
+            uint32_t stray = 0;
+            for (int k = l; k < ns; k += 64) stray += cnt[(ns - 1) * stride + k] + cnt[k * stride + (ns - 1)];
+            stray = wave_sum(stray);
+            if (l == 0) L->status = (int32_t)(stray != 0);
+        }
+        slot_sync();
+        const bool again = UNIFORM(L->status) != 0;
+        slot_sync();  // both waves have read the verdict before anything overwrites it
+        if (!again) break;
     }
-    slot_sync();  // maps written, cnt0 read by both waves: the table region can be reused
-    const int ns = (int)nsym;
-    const int stride = ns | 1;
-    const int cells = ns * stride;
-    // in LDS: packed symbols (8 B per cell, needed by the coding loop) in the table region, pair counts (4 B per cell,
-    // dead once the symbols exist) in the spare area
-    const bool in_lds = 8 * cells + 16 <= kTabBytes && 4 * cells + 16 <= kSpareBytes;
-    Prep r{in_lds ? MODE_O1_LDS : MODE_O1_GLOBAL, stride, 0, 0, 0};
-    uint32_t* cnt;
-    uint2* ent;
-    uint32_t* rep = nullptr;
-    int R = 1;
-    const int rstride = cells | 1;
-    uint8_t* big = lds_big();
-    if (in_lds) {
-        cnt = reinterpret_cast<uint32_t*>(big);
-        ent = reinterpret_cast<uint2*>(tab);
-        const int rep_off = (8 * cells + 15) & ~15;
-        while (R < 32 && rep_off + 2 * R * rstride * 4 <= kTabBytes) R <<= 1;
-        rep = reinterpret_cast<uint32_t*>(tab + rep_off);
-        r.ent_off = 0;
-    } else {
-        cnt = reinterpret_cast<uint32_t*>(B.gs);
-        ent = reinterpret_cast<uint2*>(B.gs + kGsEntOff);
-    }
-    const bool packed = !in_lds && B.n < 65536 && 2 * cells + 8 <= kBigBytes;
-    if (packed) {
-        hist_o1_packed16(B.src, B.n, cnt, stride, L->dmap, reinterpret_cast<uint32_t*>(big), cells);
-    } else {
-        for (int i = stid(); i < cells; i += kWgThreads) cnt[i] = 0;
-        if (!in_lds) __threadfence();  // the scratch was another block's a moment ago: write back / invalidate around each phase
-        hist_o1(B.src, B.n, cnt, stride, L->dmap, rep, R, rstride, cells);  // begins with a workgroup barrier
-    }
-    if (!in_lds) __threadfence();
-    slot_sync();
     if (!helper) return r;
     if (in_lds) {
         r.tab_len = tables_o1(cnt, ent, ns, ns, stride, L, B.slot + 9, B.rcp_tab, B.cap - 9 - 16);

@@ -448,6 +448,16 @@ int main(int argc, char** argv) {
         Bytes runs(3000);
         for (size_t i = 0; i < runs.size(); i++) runs[i] = (uint8_t)((i / 37) % 5 + 40);
         datas.push_back(runs);
+        if (!quick) {  // blocks beyond the alphabet sample (64 KiB): alphabet complete in the sample, a late symbol (counted
+                       // again with the full alphabet), and the same over an alphabet too wide for the LDS tables
+            for (int wide = 0; wide < 2; wide++)
+                for (int late = 0; late < 2; late++) {
+                    Bytes d(70000);
+                    for (auto& b : d) b = (uint8_t)(wide ? rng() % 200 : 30 + rng() % 9);
+                    if (late) d[69990] = 250, d[66000] = 7;
+                    datas.push_back(d);
+                }
+        }
         for (int order = 0; order < 2; order++) bad |= check_rans(c, datas, order);
         printf("rans: %s (%zu blocks x 2 orders)\n", bad ? "FAILED" : "ok", datas.size());
     }

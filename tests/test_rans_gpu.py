@@ -132,6 +132,26 @@ def test_large_quality_block(engine, orc):
     assert engine.uncompress_many(outs) == [q, q]
 
 
+def test_alphabet_sample_of_long_blocks(engine, orc):
+    """Order-1 blocks beyond 64 KiB take their alphabet from the first 64 KiB: a symbol that only turns up later must
+    send the block through the full count (Frequencies#calcFrequencies_o1 L149-193 sees every byte)."""
+    rng = np.random.default_rng(11)
+    datas = []
+    for wide in (False, True):
+        for late in (0, 1, 2):
+            d = rng.integers(0, 200, 300_000, dtype=np.uint8) if wide else rng.integers(30, 39, 300_000, dtype=np.uint8)
+            if late >= 1:
+                d[299_999] = 250   # the very last byte: a new symbol and a new context for nothing
+            if late == 2:
+                d[65_536] = 7      # the first byte behind the sample
+                d[150_000:150_004] = [1, 2, 1, 2]
+            datas.append(d.tobytes())
+    outs = engine.compress_many(datas, [1] * len(datas))
+    for d, o in zip(datas, outs):
+        assert o == orc.rans(d, 1)
+    assert engine.uncompress_many(outs) == datas
+
+
 def test_corrupt_streams_do_not_crash(engine, orc):
     d = bytes(range(64)) * 20
     for order in (0, 1):
