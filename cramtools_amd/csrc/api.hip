@@ -999,12 +999,13 @@ int32_t cramgpu_read_series_dev(cramgpu_ctx* c, int32_t n_reads, int32_t n_cont,
     hipStream_t s = pick(c, stream);
     if (int rc = enter(c, s)) return rc;
     CallScope scope{c, s};
-    HIPCHK(c->d_series_vals.reserve(read_series_ws_ints(series_bytes, n_cont)));
+    const size_t ws_ints = read_series_ws_ints(series_bytes, n_cont);
+    HIPCHK(c->d_series_vals.reserve(ws_ints));
     HIPCHK(c->d_series_cnt.reserve((size_t)n_cont * CRAMGPU_N_SERIES));
     HIPCHK(c->d_series_off.reserve((size_t)n_cont * CRAMGPU_N_SERIES));
     HIPCHK(c->d_series_base.reserve((size_t)(n_cont + 1) * 3));
     HIPCHK(launch_read_series(d_arena, d_series_off, d_series_len, n_cont, n_reads, d_cont_first, *cols, *out, *feats,
-                              c->d_series_vals.p, c->d_series_off.p, c->d_series_cnt.p, c->d_series_base.p, d_status, s));
+                              c->d_series_vals.p, (int64_t)ws_ints, c->d_series_off.p, c->d_series_cnt.p, c->d_series_base.p, d_status, s));
     return 0;
 }
 
@@ -1189,7 +1190,7 @@ int32_t cramgpu_matrices_assign_codes_dev(cramgpu_ctx* c, int32_t n_reads, const
     CallScope scope{c, s};
     HIPCHK(c->d_codes25.reserve((size_t)n_cont * 25));
     HIPCHK(launch_matrices_and_codes(d_sub_hist, n_cont, d_matrices, c->d_codes25.p, n_reads, d_read_cont, feats->off, feats->op,
-                                     feats->a, s));
+                                     feats->a, nullptr, 0, s));
     return 0;
 }
 
@@ -1396,7 +1397,7 @@ int64_t cramgpu_merge_quality_features_dev(cramgpu_ctx* c, int32_t n_reads, cons
     HIPCHK(c->d_counts.reserve((size_t)n_reads + 1));
     if (n_reads > 0)
         HIPCHK(launch_merge_quality(n_reads, d_read_len, d_base_off, d_scores, d_force, d_qstatus, *in, *out, c->d_counts.p,
-                                    false, nullptr, s));
+                                    false, nullptr, nullptr, s));
     HIPCHK(c->d_scan_ws.reserve(feature_scan_ws_elems(n_reads)));
     HIPCHK(launch_feature_scan(n_reads, c->d_counts.p, out->off, c->d_total.p, c->d_scan_ws.p, s));
     HIPCHK(hipMemcpyAsync(c->h_total.p, c->d_total.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -1405,7 +1406,7 @@ int64_t cramgpu_merge_quality_features_dev(cramgpu_ctx* c, int32_t n_reads, cons
     if (total > out->cap) return fail(CRAMGPU_E_INSUFFICIENT, "merge_quality_features: capacity too small");
     if (n_reads > 0 && total > 0)
         HIPCHK(launch_merge_quality(n_reads, d_read_len, d_base_off, d_scores, d_force, d_qstatus, *in, *out, c->d_counts.p,
-                                    true, nullptr, s));
+                                    true, nullptr, nullptr, s));
     return total;
 }
 
@@ -1677,7 +1678,8 @@ cramgpu_job* cramgpu_submit_reads(cramgpu_ctx* c, const cramgpu_host_reads* R, c
         step(launch_feature_scan(n, D.counts, D.F1.off, D.total, D.scan_ws, s));
         if (n > 0) step(launch_extract_features(dr, ref0, D.F1, D.hist, D.counts, true, D.list, list_n, D.total, s));
         // F3 + codes
-        step(launch_matrices_and_codes(D.hist, nc, D.mats, D.codes25, n, D.read_cont, D.F1.off, D.F1.op, D.F1.a, s));
+        // (the guards: the first set's offsets are the full scan even when the set did not fit and was not written)
+        step(launch_matrices_and_codes(D.hist, nc, D.mats, D.codes25, n, D.read_cont, D.F1.off, D.F1.op, D.F1.a, D.total, D.F1.cap, s));
         const cramgpu_features* Fout = &D.F1;
         if (lossy) {
             up(D.pol, h_pol, sizeof(pol));
@@ -1687,13 +1689,13 @@ cramgpu_job* cramgpu_submit_reads(cramgpu_ctx* c, const cramgpu_host_reads* R, c
                 step(launch_lossy_quals(dr, ref0, D.wpos, window, D.pol, n_pol, D.scores, D.force, D.qstatus, D.mask_ws, D.list,
                                         list_n, s));
                 step(launch_merge_quality(n, D.read_len, D.base_off, D.scores, D.force, D.qstatus, D.F1, D.F2, D.counts, false,
-                                          nullptr, s));
+                                          nullptr, D.total, s));
             }
             step(launch_feature_scan(n, D.counts, D.F2.off, D.total + 1, D.scan_ws, s));
             // the merged set only exists if the first one fitted; its own count decides its write pass
             if (n > 0)
                 step(launch_merge_quality(n, D.read_len, D.base_off, D.scores, D.force, D.qstatus, D.F1, D.F2, D.counts, true,
-                                          D.total + 1, s));
+                                          D.total + 1, D.total, s));
             Fout = &D.F2;
         }
         // phase 1 of the way back: offsets and the count

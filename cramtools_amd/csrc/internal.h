@@ -62,8 +62,8 @@ hipError_t launch_write_series(const cramgpu_reads& r, const cramgpu_record_cols
 size_t read_series_ws_ints(int64_t series_bytes, int32_t n_cont);
 hipError_t launch_read_series(const uint8_t* arena, const int64_t* d_off, const int32_t* d_len, int32_t n_cont, int32_t n_reads,
                               const int32_t* d_cont_first, const cramgpu_record_cols& c, const cramgpu_read_out& o,
-                              const cramgpu_features& f, int32_t* ws_vals, int64_t* ws_off, int32_t* ws_cnt, int64_t* ws_base,
-                              int32_t* d_status, hipStream_t s);
+                              const cramgpu_features& f, int32_t* ws_vals, int64_t ws_vals_cap, int64_t* ws_off, int32_t* ws_cnt,
+                              int64_t* ws_base, int32_t* d_status, hipStream_t s);  // ws_vals_cap: ints behind ws_vals
 void records_set_cu_count(int n_cu);  // grid sizing of the record kernels
 hipError_t launch_extract_features(const cramgpu_reads& r, const uint8_t* ref, cramgpu_features f, int64_t* sub_hist,
                                    int32_t* d_counts, bool write_pass, int32_t* list, uint32_t* list_n,
@@ -76,7 +76,8 @@ hipError_t launch_feature_scan(int32_t n_reads, const int32_t* d_counts, int64_t
 hipError_t launch_assign_codes(int32_t n_reads, const int32_t* read_cont, const int64_t* off, const uint8_t* op,
                                int32_t* a, const uint8_t* d_codes, hipStream_t s);
 hipError_t launch_matrices_and_codes(const int64_t* d_hist, int32_t n_cont, uint8_t* d_mat5, uint8_t* d_codes25, int32_t n_reads,
-                                     const int32_t* read_cont, const int64_t* off, const uint8_t* op, int32_t* a, hipStream_t s);
+                                     const int32_t* read_cont, const int64_t* off, const uint8_t* op, int32_t* a,
+                                     const int64_t* d_total_guard, int64_t cap, hipStream_t s);  // guard: touch no feature if *guard > cap
 hipError_t launch_restore_bases(int32_t n_reads, const int32_t* read_len, const int32_t* aln_start, const uint8_t* rflags,
                                 const int32_t* read_cont, const cramgpu_refwin* wins, cramgpu_features f,
                                 const uint8_t* seq, const int64_t* seq_off, int64_t seq_bytes, const uint8_t* ref,
@@ -89,7 +90,8 @@ hipError_t launch_lossy_quals(const cramgpu_reads& r, const uint8_t* ref, const 
                               uint8_t* d_mask_ws, int32_t* d_list, uint32_t* d_list_n, hipStream_t s);
 hipError_t launch_merge_quality(int32_t n_reads, const int32_t* read_len, const int64_t* base_off, const uint8_t* scores,
                                 const uint8_t* force, const int32_t* qstatus, cramgpu_features in, cramgpu_features out,
-                                int32_t* d_counts, bool write_pass, const int64_t* d_total_guard, hipStream_t s);
+                                int32_t* d_counts, bool write_pass, const int64_t* d_total_guard, const int64_t* d_in_total_guard,
+                                hipStream_t s);  // in-guard: the input set overflowed its capacity and does not exist
 
 // container assembly / BAM records (bam.hip)
 hipError_t launch_cigars(int32_t n, const int32_t* read_len, const int32_t* aln_start, const int32_t* bam_flags,

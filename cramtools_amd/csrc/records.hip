@@ -512,9 +512,10 @@ __global__ void matrices_kernel(const int64_t* hist, int32_t n_cont, uint8_t* ma
 
 // Writer#write L139-261 -> SubstitutionMatrix#code with the device tables of matrices_kernel
 __global__ void assign_codes25_kernel(int32_t n_reads, const int32_t* read_cont, const int64_t* off, const uint8_t* op,
-                                      int32_t* a, const uint8_t* codes25) {
+                                      int32_t* a, const uint8_t* codes25, const int64_t* total, int64_t cap) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
+    if (total && *total > cap) return;  // the features did not fit and were never written (see extract_kernel): off[] is the full scan
     const uint8_t* cd = codes25 + (size_t)(read_cont ? read_cont[r] : 0) * 25;
     for (int64_t f = off[r]; f < off[r + 1]; f++) {
         if (op[f] != 'X') continue;
@@ -1350,9 +1351,17 @@ __global__ __launch_bounds__(256) void lossy_quals_lane_kernel(cramgpu_reads R, 
 template <bool WRITE>
 __global__ void merge_quality_kernel(int32_t n_reads, const int32_t* read_len, const int64_t* base_off,
                                      const uint8_t* scores, const uint8_t* force, const int32_t* qstatus,
-                                     cramgpu_features in, cramgpu_features out, int32_t* counts, const int64_t* total) {
+                                     cramgpu_features in, cramgpu_features out, int32_t* counts, const int64_t* total,
+                                     const int64_t* in_total) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
+    if (in_total && *in_total > in.cap) {
+        // the input set did not fit and was never written: in.off[] runs past its columns.  Count an upper bound (every
+        // input feature plus a score per base where scores are added) without touching them: the total then exceeds the
+        // capacity as well, the job reports CRAMGPU_E_INSUFFICIENT and a capacity of off[n] is enough for the retry
+        if (!WRITE) counts[r] = (int32_t)(in.off[r + 1] - in.off[r]) + ((qstatus[r] == 0 && !force[r]) ? read_len[r] : 0);
+        return;
+    }
     if (WRITE && total && *total > out.cap) return;  // see extract_kernel
     int64_t f = in.off[r];
     const int64_t fe = in.off[r + 1];
@@ -1490,11 +1499,12 @@ hipError_t launch_assign_codes(int32_t n_reads, const int32_t* read_cont, const 
 }
 
 hipError_t launch_matrices_and_codes(const int64_t* d_hist, int32_t n_cont, uint8_t* d_mat5, uint8_t* d_codes25, int32_t n_reads,
-                                     const int32_t* read_cont, const int64_t* off, const uint8_t* op, int32_t* a, hipStream_t s) {
+                                     const int32_t* read_cont, const int64_t* off, const uint8_t* op, int32_t* a,
+                                     const int64_t* d_total_guard, int64_t cap, hipStream_t s) {
     hipLaunchKernelGGL(matrices_kernel, dim3((n_cont + 63) / 64), dim3(64), 0, s, d_hist, n_cont, d_mat5, d_codes25);
     if (n_reads > 0)
         hipLaunchKernelGGL(assign_codes25_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, s, n_reads, read_cont, off, op, a,
-                           d_codes25);
+                           d_codes25, d_total_guard, cap);
     return hipGetLastError();
 }
 
@@ -1547,13 +1557,14 @@ hipError_t launch_lossy_quals(const cramgpu_reads& r, const uint8_t* ref, const 
 
 hipError_t launch_merge_quality(int32_t n_reads, const int32_t* read_len, const int64_t* base_off, const uint8_t* scores,
                                 const uint8_t* force, const int32_t* qstatus, cramgpu_features in, cramgpu_features out,
-                                int32_t* d_counts, bool write_pass, const int64_t* d_total_guard, hipStream_t s) {
+                                int32_t* d_counts, bool write_pass, const int64_t* d_total_guard, const int64_t* d_in_total_guard,
+                                hipStream_t s) {
     const int grid = (n_reads + 255) / 256;
     if (write_pass)
         hipLaunchKernelGGL(merge_quality_kernel<true>, dim3(grid), dim3(256), 0, s, n_reads, read_len, base_off, scores,
-                           force, qstatus, in, out, d_counts, d_total_guard);
+                           force, qstatus, in, out, d_counts, d_total_guard, d_in_total_guard);
     else
         hipLaunchKernelGGL(merge_quality_kernel<false>, dim3(grid), dim3(256), 0, s, n_reads, read_len, base_off, scores,
-                           force, qstatus, in, out, d_counts, d_total_guard);
+                           force, qstatus, in, out, d_counts, d_total_guard, d_in_total_guard);
     return hipGetLastError();
 }

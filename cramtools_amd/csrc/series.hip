@@ -430,6 +430,7 @@ struct RArgs {
     int32_t* vals_cnt;   // [n_cont][NS]
     int64_t* cont_base;  // [n_cont + 1][3]: bases, features, sequence bytes in front of container c
     int32_t* status;
+    int64_t vals_cap;    // ints behind vals
 };
 
 __device__ __forceinline__ bool is_int_series(int k) {
@@ -451,8 +452,12 @@ __global__ __launch_bounds__(1024) void series_ws_layout_kernel(RArgs A) {
         const int32_t c = c0 + tid;
         int64_t t = 0;
         if (c < A.n_cont)
-            for (int k = 0; k < NS; k++)
-                if (is_int_series(k) || is_item_series(k)) t += ((int64_t)A.len[(int64_t)c * NS + k] + 4) & ~(int64_t)3;
+            for (int k = 0; k < NS; k++) {
+                // the lengths come from block headers: a negative one would make the slots overlap
+                const int32_t len = A.len[(int64_t)c * NS + k];
+                if (len < 0) *A.status = CRAMGPU_E_CORRUPT;
+                if (is_int_series(k) || is_item_series(k)) t += ((int64_t)(len < 0 ? 0 : len) + 4) & ~(int64_t)3;
+            }
         part[tid] = t;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1) {
@@ -465,13 +470,17 @@ __global__ __launch_bounds__(1024) void series_ws_layout_kernel(RArgs A) {
             int64_t o = carry + part[tid] - t;
             for (int k = 0; k < NS; k++) {
                 A.vals_off[(int64_t)c * NS + k] = o;
-                if (is_int_series(k) || is_item_series(k)) o += ((int64_t)A.len[(int64_t)c * NS + k] + 4) & ~(int64_t)3;
+                const int32_t len = A.len[(int64_t)c * NS + k];
+                if (is_int_series(k) || is_item_series(k)) o += ((int64_t)(len < 0 ? 0 : len) + 4) & ~(int64_t)3;
             }
         }
         __syncthreads();
         if (tid == 0) carry += part[1023];
         __syncthreads();
     }
+    // the workspace was sized from the caller's host-side byte count: the device lengths must fit it (the parse
+    // launch writes a value per byte at most) or nothing is parsed
+    if (tid == 0 && carry > A.vals_cap && *A.status == 0) *A.status = CRAMGPU_E_INSUFFICIENT;
 }
 
 // R1: a wave per (container, series).  A value's position depends on every value before it, but only through its FIRST
@@ -493,6 +502,12 @@ __global__ __launch_bounds__(64) void series_parse_kernel(RArgs A) {
     const int l = (int)threadIdx.x;
     const int64_t slot = (int64_t)c * NS + k;
     const bool item = is_item_series(k);
+    // set by the layout launch (lengths that do not fit the workspace): one wave, one load, the same value in every lane.
+    // (Other waves of THIS launch may set it to CRAMGPU_E_CORRUPT meanwhile; whoever sees that early just stops early.)
+    if (__shfl(*A.status, 0) != 0) {
+        if (l == 0) A.vals_cnt[slot] = 0;
+        return;
+    }
     if (!item && !is_int_series(k)) {
         if (l == 0) A.vals_cnt[slot] = 0;
         return;
@@ -672,9 +687,14 @@ __global__ __launch_bounds__(kTile) void series_read_kernel(RArgs A) {
     __shared__ uint8_t job_fill[kTile];  // no array in the stream: the scores are filled with 0xFF (offsets may be negative)
     __shared__ int contig;
     __shared__ int corrupt;
-    if (*A.status != 0) return;
+    __shared__ int entry_status;
     const int32_t c = (int32_t)blockIdx.x;
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // other workgroups of this launch write the status while this one reads it: one thread reads, all branch on its copy
+    // (waves that saw different values would part ways in front of the barriers below)
+    if (tid == 0) entry_status = *A.status;
+    __syncthreads();
+    if (entry_status != 0) return;
     const int32_t first = A.cont_first[c], last = A.cont_first[c + 1];
     const bool multiref = A.c.cont_multiref != nullptr && A.c.cont_multiref[c] != 0;
     const int64_t* voff = A.vals_off + (int64_t)c * NS;
@@ -939,9 +959,9 @@ size_t read_series_ws_ints(int64_t series_bytes, int32_t n_cont) { return (size_
 
 hipError_t launch_read_series(const uint8_t* arena, const int64_t* d_off, const int32_t* d_len, int32_t n_cont, int32_t n_reads,
                               const int32_t* d_cont_first, const cramgpu_record_cols& c, const cramgpu_read_out& o,
-                              const cramgpu_features& f, int32_t* ws_vals, int64_t* ws_off, int32_t* ws_cnt, int64_t* ws_base,
-                              int32_t* d_status, hipStream_t s) {
-    RArgs A{arena, d_off, d_len, n_cont, n_reads, d_cont_first, c, o, f, ws_vals, ws_off, ws_cnt, ws_base, d_status};
+                              const cramgpu_features& f, int32_t* ws_vals, int64_t ws_vals_cap, int64_t* ws_off, int32_t* ws_cnt,
+                              int64_t* ws_base, int32_t* d_status, hipStream_t s) {
+    RArgs A{arena, d_off, d_len, n_cont, n_reads, d_cont_first, c, o, f, ws_vals, ws_off, ws_cnt, ws_base, d_status, ws_vals_cap};
     hipError_t e = hipMemsetAsync(d_status, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws_base, 0, (size_t)(n_cont + 1) * 3 * sizeof(int64_t), s);

@@ -135,3 +135,49 @@ def test_host_stripes_lossy(orc):
         del keep
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("lossy", [False, True])
+def test_host_stripes_capacity_zero_touches_nothing(orc, lossy):
+    """with a feature capacity far below the real count the first set is never written, so nothing that
+    walks its offsets (code assignment, the count pass of the quality merge) may run: the job reports
+    CRAMGPU_E_INSUFFICIENT with the real count in off[n], and the same context still gives the oracle's answer afterwards
+    (the stray writes used to land in the job arena's other columns)."""
+    from cramtools_amd import external_compression as xc
+    from cramtools_amd import records
+    eng = xc.Engine(0)
+    try:
+        rng = np.random.default_rng(31)
+        ref, st, cigars, bases, quals, rflags, mapq = _random_container(rng, 300, 9000)
+        records.ref_upload(eng, 0, ref)
+        o = orc.Reads(st, cigars, bases, quals=quals, mapq=mapq, rflags=rflags)
+        feats = orc.extract_features(o, ref)
+        n_feat = len(feats["op"])
+        assert n_feat > 300  # many features per read on average
+        kw = dict(quals=quals, mapq=mapq, rflags=rflags)
+        if lossy:
+            kw.update(lossy_spec="*8", window=0)
+        for cap in (0, 1, 7):
+            records.ref_upload(eng, 0, ref)
+            job = records.HostReadJob(eng, st, cigars, bases, [o.n], [0], feat_cap=cap, **kw)
+            with pytest.raises(records.CramGpuError) as ei:
+                job.wait()
+            assert ei.value.code == -3
+            if not lossy:
+                assert int(job.f_off[job.n]) == n_feat
+        records.ref_upload(eng, 0, ref)
+        got = records.HostReadJob(eng, st, cigars, bases, [o.n], [0], feat_cap=n_feat + int(o.read_len.sum()) + 8, **kw).wait()
+        orc.assign_codes(feats, orc.substitution_matrix(feats["hist"]))
+        if lossy:
+            pols = orc.parse_policies("*8")
+            wpos = orc.tracks_windows(o, pols, ref.size, 1000000)
+            ws, wf, wst = orc.lossy_quals(o, ref, pols, 1000000, wpos)
+            want = orc.merge_quality_features(o, ws, wf, np.where(wst < 0, 2, wst).astype(np.int32), feats)
+        else:
+            want = feats
+        k = len(want["op"])
+        assert np.array_equal(got["off"], want["off"])
+        for key in ("op", "pos", "a", "b"):
+            assert np.array_equal(got[key][:k], want[key]), key
+    finally:
+        eng.close()

@@ -215,6 +215,20 @@ def test_reader_matches_oracle_and_inverts_writer(orc, seed, sizes):
             rd.check()
         w.len[3] += 1
         w.len[0] += 1
+        # the value workspace is sized from the caller's byte count, the parse from the device
+        # lengths: lengths that sum to more than that, or a negative one, are reported before anything is parsed
+        if n > 50:  # (a one-record container fits the slack every workspace has)
+            rd.read(w.arena, w.off, w.len, cont_first, 16, multiref=multiref, ap_base=ap_base, ap_delta=ap_delta)
+            with pytest.raises(RuntimeError):
+                rd.check()
+        keep = int(w.len[5])
+        w.len[5] = -8
+        rd.read(w.arena, w.off, w.len, cont_first, int(w.arena.numel()), multiref=multiref, ap_base=ap_base, ap_delta=ap_delta)
+        with pytest.raises(RuntimeError):
+            rd.check()
+        w.len[5] = keep
+        rd.read(w.arena, w.off, w.len, cont_first, int(w.arena.numel()), multiref=multiref, ap_base=ap_base, ap_delta=ap_delta)
+        rd.check()  # and the reader works as before afterwards
         if feats.count > 4:
             small = records.CramRecordReader(eng, DEV, n, n_cont, int(reads.bases.numel()), 2, int(reads.bases.numel()))
             small.read(w.arena, w.off, w.len, cont_first, int(w.arena.numel()), multiref=multiref, ap_base=ap_base, ap_delta=ap_delta)
