@@ -757,6 +757,212 @@ def pcie_inclusive(eng, w, per_job=256, n_cont=None, outstanding=4, reps=2, pack
                 note="raw blocks from pinned host arenas, streams back into pinned host arenas (H2D + kernels + D2H)")
 
 
+# ======================================================================================================
+# --config 4: BASELINE.json configs[4] (10 kbp reads, high indel rate, lossy model R8-N40-D8, order-1 rANS) as one timed
+# pipeline.  Not the headline (that stays configs[1]); here so that the config's number is reproducible.
+# ======================================================================================================
+def long_read_set(rng, n, L, ref):
+    """n start-sorted reads of exactly L bases: match runs (geometric, mean 12.5) with 3 %
+    substitutions, cut by an insertion or a deletion of 1-3 bases each, uniform scores 1-30.  Vectorised numpy: the reads
+    of one container are 10^8 bases.  Returns flat arrays shaped like synth.ReadSet."""
+    K = int(L / 13.0 * 1.25) + 64
+    run = rng.geometric(0.08, (n, K)).astype(np.int64)
+    ins = rng.random((n, K)) < 0.5
+    k = rng.integers(1, 4, (n, K)).astype(np.int64)
+    used = run + np.where(ins, k, 0)  # read bases of a segment: its match run and the insertion behind it
+    cum = np.cumsum(used, 1)
+    assert (cum[:, -1] >= L).all()
+    last = (cum < L).sum(1)  # the segment that reaches L: its run is cut to fit and nothing follows it
+    j = np.arange(K)[None, :]
+    before = np.where(last > 0, cum[np.arange(n), np.maximum(last - 1, 0)], 0)
+    run[np.arange(n), last] = L - before
+    valid = j <= last[:, None]
+    indel = valid & (j < last[:, None])
+    refspan = np.where(valid, run, 0) + np.where(indel & ~ins, k, 0)
+    span = refspan.sum(1)
+    starts = np.sort(rng.integers(1, ref.size - int(span.max()) - 16, n)).astype(np.int64)
+    ref_at = starts[:, None] - 1 + np.cumsum(refspan, 1) - refspan  # 0-based reference position of each match run
+    # CIGAR: M run, then I k / D k behind every segment but the last
+    ops = np.stack([(run << 4) | 0, (k << 4) | np.where(ins, 1, 2)], 2)
+    keep = np.stack([valid, indel], 2)
+    cigar = ops[keep].astype(np.uint32)
+    n_cigar = keep.reshape(n, -1).sum(1).astype(np.int32)
+    # pieces of the read in order: match run (copied from the reference), insertion (random bases)
+    plen = np.stack([np.where(valid, run, 0), np.where(indel & ins, k, 0)], 2).reshape(-1)
+    psrc = np.stack([ref_at, np.full((n, K), -1, np.int64)], 2).reshape(-1)
+    nz = plen > 0
+    plen, psrc = plen[nz], psrc[nz]
+    total = n * L
+    assert int(plen.sum()) == total
+    pstart = np.cumsum(plen) - plen
+    within = np.arange(total, dtype=np.int64) - np.repeat(pstart, plen)
+    src = np.repeat(psrc, plen)
+    is_match = src >= 0
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    bases = acgt[rng.integers(0, 4, total)]
+    bases[is_match] = ref[(src + within)[is_match]]
+    sub = is_match & (rng.random(total) < 0.03)
+    bases[sub] = acgt[(np.searchsorted(acgt, bases[sub]) + rng.integers(1, 4, int(sub.sum()))) % 4]
+    quals = rng.integers(1, 31, total, dtype=np.uint8)
+    return dict(n=n, bases=bases, quals=quals, base_off=np.arange(n, dtype=np.int64) * L, read_len=np.full(n, L, np.int32),
+                aln_start=starts.astype(np.int32), aln_span=(span - 1).astype(np.int32), cigar=cigar,  # alignmentEnd - alignmentStart
+                cigar_off=(np.cumsum(n_cigar) - n_cigar).astype(np.int64), n_cigar=n_cigar,
+                mapq=np.where(rng.random(n) < 0.05, 0, 60).astype(np.uint8))
+
+
+class StepC5:
+    """One pass of configs[4]'s encode path over the resident reads: K3 -> F3 -> K5 (lossy model) -> merge of the Q
+    features -> data-series writer (QS from the model's scores) -> rANS over the ten series -> gather."""
+
+    def __init__(self, dev, eng, ref, rs, spec, n_cont):
+        self.dev, self.eng, self.spec = dev, eng, spec
+        n = rs["n"]
+        pad = np.zeros(16, np.uint8)
+        windows = [(0, ref.numel() - 16, 0)] * n_cont
+        read_cont = (np.arange(n) // READS_PER_CONTAINER).astype(np.int32)
+        mk = lambda q: rec.ReadBatch(dev, np.concatenate([rs["bases"], pad]), rs["base_off"], rs["read_len"], rs["aln_start"],
+                                     np.concatenate([rs["cigar"], np.zeros(1, np.uint32)]).view(np.int32), rs["cigar_off"],
+                                     rs["n_cigar"], quals=q, mapq=rs["mapq"], read_cont=read_cont, windows=windows)
+        self.reads = mk(np.concatenate([rs["quals"], pad]))
+        self.lossy_reads = mk(None)  # the same reads with the model's scores in place of the input scores
+        self.ref, self.n, self.n_cont = ref, n, n_cont
+        self.fac = rec.Sam2CramRecordFactory(eng)
+        self.fac.set_ref_bases(ref)
+        self.qsp = rec.QualityScorePreservation(eng, spec)
+        self.wpos = self.qsp.tracks_windows(rs["aln_start"], rs["aln_span"], np.zeros(n, np.uint8), rs["mapq"], ref.numel() - 16)
+        self.tot = int(rs["read_len"].sum())
+        self.feat_cap = self.tot // 4
+        first = np.arange(n_cont) * READS_PER_CONTAINER
+        self.cols_np = dict(bam_flags=np.zeros(n, np.int32), read_group=np.full(n, -1, np.int32), mate_ref=np.full(n, -1, np.int32))
+        self.ap_base = rs["aln_start"][first].astype(np.int32)
+        self.ids = np.array([_lib.SERIES_ID[name] for name, _ in SERIES])
+        self.writer = rec.Writer(eng, dev, n_cont, 3 * self.tot + 24 * (self.feat_cap + self.tot // 8) + 70 * n + 4096 * n_cont)
+        nb = n_cont * len(SERIES)
+        self.nb = nb
+        self.blk = np.zeros(nb, BLOCK_DTYPE)
+        self.blk["order"] = np.tile(np.array([o for _, o in SERIES], np.int32), n_cont)
+        cap_total = int(1.06 * (self.tot + 40 * n + 8 * self.feat_cap)) + nb * (257 * 257 * 3 + 64)
+        self.d_out = torch.empty(cap_total, dtype=torch.uint8, device=dev)
+        self.d_len = torch.zeros(nb, dtype=torch.int32, device=dev)
+        self.d_pos = torch.zeros(nb, dtype=torch.int64, device=dev)
+        self.d_pack = torch.empty(self.tot + (64 << 20), dtype=torch.uint8, device=dev)
+        self.d_pack_off = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self.enc_ms, self.raw_bytes = [], 0
+
+    def run(self, timed):
+        reads = self.reads
+        feats, hist = self.fac.create_variations(reads, feature_cap=self.feat_cap)
+        mats = np.stack([rec.substitution_matrix(hist[c]) for c in range(self.n_cont)])
+        self.fac.assign_codes(reads, feats, mats)
+        scores, force, status = self.qsp.add_quality_scores(reads, self.ref, self.wpos)
+        merged = self.qsp.merge_quality_features(reads, scores, force, status, feats)
+        self.lossy_reads.quals = scores
+        cols = rec.RecordColumns(self.dev, self.n, ap_base=self.ap_base, comp_flags=2 | force.to(torch.int32), **self.cols_np)
+        self.writer.write(self.lossy_reads, cols, merged)
+        off, ln = self.writer.lengths()
+        blk = self.blk
+        blk["in_off"], blk["in_len"] = off[:, self.ids].reshape(-1), ln[:, self.ids].reshape(-1)
+        cap = (1.05 * blk["in_len"].astype(np.float64) + 257.0 * 257.0 * 3.0 + 4.0).astype(np.int32)  # RANS#allocateIfNeeded
+        blk["out_cap"] = cap
+        slot = (cap.astype(np.int64) + 15) // 16 * 16
+        blk["out_off"] = np.cumsum(slot) - slot
+        assert int(blk["out_off"][-1] + slot[-1]) + 16 <= self.d_out.numel()
+        if timed:
+            self.ev[0].record()
+        self.eng.encode_dev(self.writer.arena, self.d_out, blk, self.nb, self.d_len, self.d_pos)
+        if timed:
+            self.ev[1].record()
+        self.eng.gather_dev(self.d_out, self.d_pos, self.d_len, self.nb, int(cap.max()), self.d_pack, self.d_pack_off)
+        self.raw_bytes = int(blk["in_len"].sum())
+        self.last = (feats, mats, scores, force, status, merged, off, ln)
+        if timed:
+            torch.cuda.synchronize()
+            self.enc_ms.append(self.ev[0].elapsed_time(self.ev[1]))
+
+    def verify(self, rs, ref_np):
+        """Container 0 against the oracle: merged features, every series of the writer, every rANS stream."""
+        from oracle import orc
+        m = min(READS_PER_CONTAINER, rs["n"])
+        co, nc = rs["cigar_off"], rs["n_cigar"]
+        cig = [list(rs["cigar"][co[r]:co[r] + nc[r]]) for r in range(m)]
+        L = int(rs["read_len"][0])
+        bs = [rs["bases"][r * L:(r + 1) * L].tobytes() for r in range(m)]
+        qs = [rs["quals"][r * L:(r + 1) * L].tobytes() for r in range(m)]
+        o = orc.Reads(rs["aln_start"][:m], cig, bs, quals=qs, mapq=rs["mapq"][:m])
+        wf = orc.extract_features(o, ref_np)
+        wm = orc.substitution_matrix(wf["hist"])
+        orc.assign_codes(wf, wm)
+        pols = orc.parse_policies(self.spec)
+        wpos = orc.tracks_windows(o, pols, ref_np.size)
+        ws, wforce, wst = orc.lossy_quals(o, ref_np, pols, 1000000, wpos)
+        merged_w = orc.merge_quality_features(o, ws, wforce, wst, wf)
+        feats, mats, scores, force, status, merged, off, ln = self.last
+        assert np.array_equal(mats[0], wm)
+        gm = merged.to_host()
+        k = len(merged_w["op"])
+        assert int(gm["off"][m]) == k
+        for key in ("op", "pos", "a", "b"):
+            assert np.array_equal(gm[key][:k], merged_w[key]), key
+        full = {c: np.zeros(m, np.int32) for c in rec.RECORD_COLS}
+        full.update(bam_flags=np.zeros(m, np.int32), read_group=np.full(m, -1, np.int32), mate_ref=np.full(m, -1, np.int32),
+                    comp_flags=(2 | wforce.astype(np.int32)))
+        want = orc.write_series(full, o.read_len, o.aln_start, rs["mapq"][:m], o.bases, ws, o.base_off, merged_w)
+        lens, pos = self.d_len.cpu().numpy(), self.d_pos.cpu().numpy()
+        for i, (name, od) in enumerate(SERIES):
+            sid = _lib.SERIES_ID[name]
+            assert self.writer.series(0, sid) == want[sid], name
+            got = self.d_out[int(pos[i]):int(pos[i]) + int(lens[i])].cpu().numpy().tobytes()
+            assert got == orc.rans(want[sid], od), name
+        return "container 0: merged features, the ten rANS series of the writer and their streams byte-identical to the CPU oracle"
+
+
+def main_config4(a, rank, world, dist, be):
+    """bench.py --config 4: the JSON line of configs[4] (same shape as the headline's)."""
+    n = a.reads if a.reads != 10_000_000 else 20_000
+    L = a.read_len if a.read_len != 150 else 10_000
+    assert n % READS_PER_CONTAINER == 0 or n < READS_PER_CONTAINER, "whole containers (CramContext.java:33)"
+    n_cont = max(1, n // READS_PER_CONTAINER)
+    rng = np.random.default_rng(1 + 10 * rank)
+    ref_np = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, max(n * L // 8, 4 * L) + 16 * L)]
+    rs = long_read_set(rng, n, L, ref_np)
+    ref = torch.as_tensor(np.concatenate([ref_np, np.zeros(16, np.uint8)])).to(be.dev)
+    spec = "R8-N40-D8"
+    step = StepC5(be.dev, be.eng, ref, rs, spec, n_cont)
+    for _ in range(a.warmup):
+        step.run(False)
+    dt = sharding.timed_region(lambda: step.run(True), a.steps, dist=dist, sync=be.sync)
+    lens = step.d_len.cpu().numpy()
+    assert (lens >= 0).all()
+    comp = int(lens.sum())
+    line = None
+    if rank == 0:
+        parity = step.verify(rs, ref_np)
+        enc_s = float(np.mean(step.enc_ms)) / 1e3
+        algo = step.raw_bytes + comp
+        raw = step.raw_bytes * world
+        line = dict(metric="CRAM encode hot path: uncompressed external-block payload MB/s (rANS o0/o1 + feature extraction)",
+                    value=raw * a.steps / dt / 1e6, unit="MB/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                    ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8", data="synthetic",
+                    config=dict(workload="configs[4]: %d x %d bp reads (3 %% substitutions, an insertion or deletion of 1-3 bases every "
+                                         "12.5 bases), lossy model %s, %d container(s) x %d rANS blocks: K3 -> F3 -> K5 -> merge -> "
+                                         "series writer -> rANS -> gather" % (n, L, spec, n_cont, len(SERIES)), reads_per_gpu=n,
+                                parallelism="containers sharded by index, %d rank(s), no collective" % world),
+                    reads_per_s=n * world * a.steps / dt, bases_per_s=n * L * world * a.steps / dt,
+                    compression_ratio=step.raw_bytes / max(comp, 1),
+                    roofline=dict(bound="hbm", achieved=algo / enc_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                  frac=algo / enc_s / 1e9 / HBM_PEAK_GBS, traffic=None, kernel="rans_encode_kernel",
+                                  ms_per_launch=enc_s * 1e3, algorithmic_bytes=algo,
+                                  note="one 10^8-byte quality block per container is ONE serial rANS chain of 2.5 x 10^7 steps: "
+                                       "latency bound by construction (SURVEY.md section 7)"),
+                    parity=parity)
+        print(json.dumps(line), flush=True)
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return line
+
+
 PMC_ROUND = "r03"  # the round whose committed --pmc passes describe the kernels as they are now
 
 
@@ -829,6 +1035,8 @@ def main(argv=None, backend_factory=GpuBackend):
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-pcie", action="store_true")
     ap.add_argument("--no-bgzf", action="store_true", help="skip the BGZF image of the BAM stripe (2.7 GB through the gzip kernel)")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 4),
+                    help="1: the headline (BASELINE.json configs[1] + the configs[2] decode leg); 4: configs[4], long reads + lossy model")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -840,6 +1048,8 @@ def main(argv=None, backend_factory=GpuBackend):
         if not dist.is_initialized():
             dist.init_process_group(backend_factory.dist_backend)
     be = backend_factory(local)
+    if a.config == 4:
+        return main_config4(a, rank, world, dist, be)
 
     # every rank codes its own containers (seed shifted by rank): weak scaling, no collective on the data path
     w = be.workload(a, 10 * rank)

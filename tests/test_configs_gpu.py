@@ -107,6 +107,119 @@ def test_config5_long_reads_lossy_pipeline(orc):
         eng.close()
 
 
+RANS_SERIES = [("QS", 1), ("AP", 0), ("RI", 0), ("BA", 1), ("BF", 1), ("CF", 1), ("NS", 1), ("RG", 1), ("RL", 1), ("TS", 1)]
+
+
+def test_config5_one_pipeline(orc):
+    """configs[4] as ONE pipeline on one container of 1000 x 10 kbp reads: K3 -> F3 -> K5 -> merge ->
+    data-series writer (the QS series is the arrays of the forced reads plus the Q features of the others:
+    QualityScorePreservation.java:276-301, Writer#write L139-261) -> order-0/1 rANS -> gather -> rANS decode -> reader ->
+    restoreReadBases / restoreQualityScores.  Every series against orc.write_series, every stream against orc.rans, the
+    restored scores against orc.restore_quals, the restored bases against the reads.  Under the config's policy
+    (every read force-preserved) and under N40-D8 (none forced: the scores travel as Q features)."""
+    import torch
+    from cramtools_amd import _lib, external_compression as xc, records
+    rng = np.random.default_rng(77)
+    n, L = 1000, 10000
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), 10_100_000)
+    starts, cigars, bases, quals = _long_read_container(rng, n, L, ref)
+    mapq = np.where(rng.random(n) < 0.05, 0, 60).astype(np.uint8)
+    o = orc.Reads(starts, cigars, bases, quals=quals, mapq=mapq)
+    tot = int(o.read_len.sum())
+    want_f = orc.extract_features(o, ref)
+    want_m = orc.substitution_matrix(want_f["hist"])
+    orc.assign_codes(want_f, want_m)
+    eng = xc.Engine(0)
+    try:
+        reads = records.ReadBatch.from_lists(DEV, starts, cigars, bases, quals=quals, mapq=mapq, ref_len=ref.size)
+        d_ref = torch.as_tensor(np.concatenate([ref, np.zeros(16, np.uint8)])).to(DEV)
+        fac = records.Sam2CramRecordFactory(eng)
+        fac.set_ref_bases(d_ref)
+        feats, hist = fac.create_variations(reads, feature_cap=n * L // 4)
+        m = records.substitution_matrix(hist[0])
+        assert np.array_equal(m, want_m)
+        fac.assign_codes(reads, feats, m)
+        cont_first = torch.as_tensor(np.array([0, n], np.int32)).to(DEV)
+        for spec in ("R8-N40-D8", "N40-D8"):
+            # ---- lossy model and merge
+            qsp = records.QualityScorePreservation(eng, spec)
+            pols = orc.parse_policies(spec)
+            wpos = qsp.tracks_windows(starts, o.aln_span, o.rflags, mapq, ref.size)
+            scores, force, status = qsp.add_quality_scores(reads, d_ref, wpos)
+            ws, wf, wst = orc.lossy_quals(o, ref, pols, 1000000, wpos)
+            assert (wst == 0).all() and np.array_equal(status.cpu().numpy(), wst)
+            assert bool(wf.all()) == (spec == "R8-N40-D8") and (spec == "R8-N40-D8" or not wf.any())
+            merged = qsp.merge_quality_features(reads, scores, force, status, feats)
+            wm = orc.merge_quality_features(o, ws, wf, wst, want_f)
+            # ---- data-series writer: compression flags carry the force-preserve bit, the score arrays are the model's
+            cols = dict(bam_flags=np.full(n, 0), comp_flags=2 | wf.astype(np.int32), read_group=np.full(n, -1),
+                        mate_ref=np.full(n, -1), mate_start=np.zeros(n), tlen=np.zeros(n), tag_list=np.zeros(n))
+            rc = records.RecordColumns(DEV, n, **cols)
+            lossy_reads = records.ReadBatch.from_lists(DEV, starts, cigars, bases, quals=quals, mapq=mapq, ref_len=ref.size)
+            lossy_reads.quals = scores
+            w = records.Writer(eng, DEV, 1, 3 * tot + 24 * merged.count + 70 * n + 4096)
+            w.write(lossy_reads, rc, merged)
+            off, ln = w.lengths()
+            full = {k: np.asarray(cols.get(k, np.zeros(n)), np.int32) for k in records.RECORD_COLS}
+            want = orc.write_series(full, o.read_len, o.aln_start, mapq, o.bases, ws, o.base_off, wm)
+            for k in range(_lib.N_SERIES):
+                assert w.series(0, k) == want[k], (spec, k)
+            qs_id = _lib.SERIES_ID["QS"]
+            assert len(want[qs_id]) == (tot if spec == "R8-N40-D8" else int((wm["op"] == ord("Q")).sum()))
+            # ---- rANS over the ten series the reference codes with it, straight from the writer's arena
+            ids = [(_lib.SERIES_ID[s], od) for s, od in RANS_SERIES]
+            lens = [int(ln[0, k]) for k, _ in ids]
+            blocks, _, out_bytes = xc.Engine.plan_encode(lens, [od for _, od in ids])
+            for i, (k, _) in enumerate(ids):
+                blocks[i].in_off = int(off[0, k])
+            nb = len(ids)
+            d_out = torch.zeros(out_bytes, dtype=torch.uint8, device=DEV)
+            d_len = torch.zeros(nb, dtype=torch.int32, device=DEV)
+            d_pos = torch.zeros(nb, dtype=torch.int64, device=DEV)
+            eng.encode_dev(w.arena, d_out, blocks, nb, d_len, d_pos)
+            clen, cpos = d_len.cpu().numpy(), d_pos.cpu().numpy()
+            for i, (k, od) in enumerate(ids):
+                got = d_out[int(cpos[i]):int(cpos[i]) + int(clen[i])].cpu().numpy().tobytes()
+                assert got == orc.rans(want[k], od), (spec, k)
+            # ---- the way back: gather, rANS decode into a fresh arena beside the other series, reader, normalizer
+            d_pack = torch.zeros(int(clen.sum()) + 32 * nb + 64, dtype=torch.uint8, device=DEV)
+            d_pack_off = torch.zeros(nb + 1, dtype=torch.int64, device=DEV)
+            eng.gather_dev(d_out, d_pos, d_len, nb, int(max(b.out_cap for b in blocks[:nb])), d_pack, d_pack_off)
+            poff = d_pack_off.cpu().numpy()
+            arena2 = w.arena.clone()
+            for i, (k, _) in enumerate(ids):
+                arena2[int(off[0, k]):int(off[0, k]) + int(ln[0, k])] = 0xAA  # only the decoder can bring these back
+            dblocks = (_lib.Block * nb)()
+            for i, (k, _) in enumerate(ids):
+                dblocks[i] = _lib.Block(int(poff[i]), int(off[0, k]), int(clen[i]), int(ln[0, k]), 0, 0)
+            d_rawlen = torch.zeros(nb, dtype=torch.int32, device=DEV)
+            eng.decode_dev(d_pack, arena2, dblocks, nb, d_rawlen)
+            assert np.array_equal(d_rawlen.cpu().numpy(), np.array(lens, np.int32))
+            rd = records.CramRecordReader(eng, DEV, n, 1, tot, merged.count + 8, tot)
+            ap0 = int(o.aln_start[0])  # the slice header's alignment start: what the first AP delta counts from
+            rd.read(arena2, w.off, w.len, cont_first, int(arena2.numel()), ap_base=np.array([ap0], np.int32))
+            rd.check()
+            wr = orc.read_series(want, n, ap_base=ap0)
+            assert rd.feats.count == wr["n_feat"] == len(wm["op"])
+            gf = rd.feats.to_host()
+            for key in ("op", "pos", "a", "b"):
+                assert np.array_equal(gf[key][:wr["n_feat"]], wr[key][:wr["n_feat"]]), (spec, key)
+            assert np.array_equal(rd.read_len.cpu().numpy(), o.read_len) and np.array_equal(rd.aln_start.cpu().numpy(), o.aln_start)
+            norm = records.CramNormalizer(eng)
+            rl, st, fl = rd.read_len.cpu().numpy(), rd.aln_start.cpu().numpy(), rd.rflags.cpu().numpy()
+            out, out_off, bst = norm.restore_read_bases(DEV, rl, st, fl, rd.feats, d_ref, [(0, ref.size, 0)], m, seq=rd.seq,
+                                                        seq_off=rd.seq_off[:n])
+            assert (bst.cpu().numpy() == 0).all()
+            assert np.array_equal(out.cpu().numpy()[:tot], o.bases[:tot])  # upper-case ACGT reads: restoration is exact
+            sc, qst = norm.restore_quality_scores(DEV, rl, fl, rd.feats, rd.quals[:tot + 16])
+            o_fl = (o.rflags | np.where(wf != 0, orc.RF_FORCE_QS, 0)).astype(np.uint8)
+            want_q, want_qst = orc.restore_quals(o.read_len, o_fl, wm, ws)
+            assert np.array_equal(qst.cpu().numpy(), want_qst)
+            assert np.array_equal(sc.cpu().numpy()[:tot], want_q[:tot]), spec
+    finally:
+        eng.close()
+
+
 def test_config5_100mb_blocks(orc):
     """The QS block of a 10 000 x 10 kbp container is one ~100 MB rANS stream: encode and decode one order-1 and one
     order-0 block of that size and compare both directions with the oracle (E14#compress L13-86,
