@@ -165,6 +165,8 @@ SYMBOLS = {
     "cramgpu_read_series_dev": (I32, [P, I32, I32, P, P, P, P, I64, P, P, P, P, P]),
     "cramgpu_cigars_dev": (I32, [P, I32, P, P, P, P, P, P, P, I64, P, P, P]),
     "cramgpu_restore_mates_dev": (I32, [P, I32, I32, P, P, P, P, P, P, P]),
+    "cramgpu_set_mate_info_dev": (I32, [P, I32, I32, P, P, P, P, P, P, P, P]),
+    "cramgpu_content_digests_dev": (I32, [P, I32, I32, P, P, P, P, P, P, P]),
     "cramgpu_bam_encode_dev": (I32, [P, I32, P, P, I64, P, P, P]),
     "cramgpu_bam_decode_dev": (I32, [P, I32, P, P, P, P, P]),
     "cramgpu_bam_index": (I64, [P, I64, P, I64]),

@@ -53,6 +53,47 @@ class Cram2SamRecordFactory:
         return status
 
 
+class CramSerilization:
+    """src/main/java/htsjdk/samtools/cram/CramSerilization.java (the reference spells it so): what #convert does to a
+    container's records between Sam2CramRecordFactory and ContainerFactory#buildContainer."""
+
+    def __init__(self, engine, device):
+        self.engine, self.device = engine, device
+
+    def set_mate_info(self, cols, cont_first, aln_start, aln_end, names, name_off, name_len):
+        """#setMateInfo (:274-373) for every container; cols.comp_flags / cols.next_frag are updated in place.
+        names: uint8 device tensor the offsets point into (e.g. the BAM stripe), name_off int64[n], name_len int32[n]."""
+        n_cont = int(cont_first.numel()) - 1
+        cs = cols.struct()
+        _lib.check(_lib.lib().cramgpu_set_mate_info_dev(self.engine.handle, cols.n, n_cont, cont_first.data_ptr(), C.byref(cs),
+                                                        aln_start.data_ptr(), aln_end.data_ptr(), names.data_ptr(),
+                                                        name_off.data_ptr(), name_len.data_ptr(), _stream()))
+
+    def content_digests(self, cont_first, base_off, read_len, bases, quals):
+        """ContentDigests BD / SD per container (cramgpu_content_digests_dev).  -> uint32-as-int64 tensor [n_cont, 2]."""
+        torch = _torch()
+        n_cont = int(cont_first.numel()) - 1
+        out = torch.zeros(2 * n_cont, dtype=torch.int32, device=self.device)
+        _lib.check(_lib.lib().cramgpu_content_digests_dev(self.engine.handle, int(read_len.numel()), n_cont, cont_first.data_ptr(),
+                                                          base_off.data_ptr(), read_len.data_ptr(), bases.data_ptr(),
+                                                          quals.data_ptr(), out.data_ptr(), _stream()))
+        return (out.to(torch.int64) & 0xFFFFFFFF).reshape(n_cont, 2)
+
+
+# MessageDigestHasher#asByteArray hands out messageDigest.digest() of the digest #getValue has just reset: the digest
+# of the empty message (SHA-512 / SHA-1 of b""), whatever the records held (see include/cramgpu.h).
+_SHA512_EMPTY = bytes.fromhex("cf83e1357eefb8bdf1542850d66d8007d620e4050b5715dc83f4a921d36ce9ce"
+                              "47d0d13c5d85f2b0ff8318d2877eec2f63b931bd47417a81a538327af927da3e")
+_SHA1_EMPTY = bytes.fromhex("da39a3ee5e6b4b0d3255bfef95601890afd80709")
+
+
+def slice_content_tags(bd, sd):
+    """The six tags ContentDigests.create(ALL).getAsTags() gives a slice, as (tag, byte-array value) in the order of
+    KNOWN_DIGESTS: BD / SD = the CRC sums little-endian (Crc32Hasher#asByteArray), B5 S5 B1 S1 as described above."""
+    le = lambda v: int(v & 0xFFFFFFFF).to_bytes(4, "little")
+    return [("BD", le(bd)), ("SD", le(sd)), ("B5", _SHA512_EMPTY), ("S5", _SHA512_EMPTY), ("B1", _SHA1_EMPTY), ("S1", _SHA1_EMPTY)]
+
+
 class BAMRecordCodec:
     """htsjdk!BAMRecordCodec over whole stripes: encode() = one BAM alignment record per record, back to back (layout:
     encoding/reader/BAMRecordView.java:23-35 ...), decode() = the columns of a stripe of records."""

@@ -1047,6 +1047,38 @@ int32_t cramgpu_restore_mates_dev(cramgpu_ctx* c, int32_t n_reads, int32_t n_con
     return 0;
 }
 
+int32_t cramgpu_set_mate_info_dev(cramgpu_ctx* c, int32_t n_reads, int32_t n_cont, const int32_t* d_cont_first,
+                                  const cramgpu_record_cols* cols, const int32_t* d_aln_start, const int32_t* d_aln_end,
+                                  const uint8_t* d_names, const int64_t* d_name_off, const int32_t* d_name_len, void* stream) {
+    if (!c || n_reads < 0 || n_cont < 1 || !d_cont_first || !cols || !d_aln_start || !d_aln_end || !d_names || !d_name_off ||
+        !d_name_len)
+        return fail(CRAMGPU_E_ARG, "set_mate_info: bad argument");
+    if (!cols->bam_flags || !cols->comp_flags || !cols->ref_id || !cols->mate_flags || !cols->mate_ref || !cols->mate_start ||
+        !cols->tlen || !cols->next_frag)
+        return fail(CRAMGPU_E_ARG, "set_mate_info: a column is missing");
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(c->d_list.reserve(3 * mate_table_slots(n_reads) + (size_t)n_reads + 1));
+    HIPCHK(launch_set_mate_info(n_reads, n_cont, d_cont_first, *cols, d_aln_start, d_aln_end, d_names, d_name_off, d_name_len,
+                                c->d_list.p, s));
+    return 0;
+}
+
+int32_t cramgpu_content_digests_dev(cramgpu_ctx* c, int32_t n_reads, int32_t n_cont, const int32_t* d_cont_first,
+                                    const int64_t* d_base_off, const int32_t* d_read_len, const uint8_t* d_bases,
+                                    const uint8_t* d_quals, uint32_t* d_crc, void* stream) {
+    if (!c || n_reads < 0 || n_cont < 1 || !d_cont_first || !d_base_off || !d_read_len || !d_bases || !d_quals || !d_crc)
+        return fail(CRAMGPU_E_ARG, "content_digests: bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(launch_content_crc(n_reads, n_cont, d_cont_first, d_base_off, d_read_len, d_bases, d_quals, d_crc, s));
+    return 0;
+}
+
 int32_t cramgpu_bam_encode_dev(cramgpu_ctx* c, int32_t n_reads, const cramgpu_bam_cols* b, uint8_t* d_bam, int64_t bam_cap,
                                int64_t* d_rec_off, int32_t* d_status, void* stream) {
     if (!c || n_reads < 0 || !b || !d_bam || bam_cap < 0 || !d_rec_off || !d_status)

@@ -615,6 +615,127 @@ __global__ __launch_bounds__(64) void slice_md5_kernel(int32_t n, const uint8_t*
     *out = o;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// setMateInfo — src/main/java/htsjdk/samtools/cram/CramSerilization.java:274-373 (and #detach :265-272): which records of a
+// container leave as a (mate downstream, NF) pair and which as detached records.  The reference walks the records in
+// order through two TreeMap<readName, record> (primary / secondary alignments) and links the second record of a name to
+// the first; a third record of the name detaches all of them (:294-298; the links stay, every later check can only
+// detach again); a pair survives the checks of :320-346 or both ends are detached; a name seen once is detached
+// (:350-370).  Per (container, secondary?, name) that is a function of the group's size and of its two lowest record
+// indices, which is what is computed here: an open-addressing table over the batch (exact comparison of the name
+// bytes on a hit), a count and the lowest index per group, then one thread per pair evaluates the checks.
+// ---------------------------------------------------------------------------------------------------------------
+struct MateInfo {
+    const int32_t *bam_flags, *ref_id, *aln_start, *aln_end, *mate_flags, *mate_ref, *mate_start, *tlen;
+    int32_t *comp_flags, *next_frag;
+    const uint8_t* names;
+    const int64_t* name_off;
+    const int32_t* name_len;
+};
+constexpr int32_t BF_FIRST_SEGMENT = 0x40, BF_LAST_SEGMENT = 0x80, BF_SECONDARY = 0x100;
+
+__device__ __forceinline__ void mate_set_lone(const MateInfo& M, int32_t r) {  // :279-282, :353-356, #detach
+    M.comp_flags[r] = (M.comp_flags[r] | CRAMGPU_CF_DETACHED) & ~CRAMGPU_CF_HAS_MATE_DOWNSTREAM;
+    M.next_frag[r] = -1;
+}
+
+__global__ __launch_bounds__(256) void mate_group_kernel(int32_t n, int32_t n_cont, const int32_t* cont_first, MateInfo M,
+                                                         int32_t* table, uint32_t mask, uint32_t* gfirst, uint32_t* gcount,
+                                                         int32_t* slot_of) {
+    const int32_t r = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n) return;
+    const int32_t bf = M.bam_flags[r];
+    if (!(bf & BF_PAIRED)) {  // :278-284
+        mate_set_lone(M, r);
+        slot_of[r] = -1;
+        return;
+    }
+    const int32_t c = cont_of(cont_first, n_cont, r);
+    const int32_t lo = cont_first[c], hi = cont_first[c + 1];
+    const uint32_t sec = (bf & BF_SECONDARY) ? 1u : 0u;
+    const uint8_t* nm = M.names + M.name_off[r];
+    const int32_t ln = M.name_len[r];
+    uint32_t h = 2166136261u ^ ((uint32_t)c * 0x9E3779B1u + sec);
+    for (int32_t i = 0; i < ln; i++) h = (h ^ nm[i]) * 16777619u;
+    h ^= h >> 15;
+    uint32_t at = h & mask;
+    for (;; at = (at + 1) & mask) {
+        int32_t j = atomicCAS(&table[at], -1, r);
+        if (j == -1) break;  // a new (container, map, name)
+        if (j < lo || j >= hi || M.name_len[j] != ln || (((uint32_t)M.bam_flags[j] & BF_SECONDARY) ? 1u : 0u) != sec) continue;
+        const uint8_t* o = M.names + M.name_off[j];
+        int32_t i = 0;
+        while (i < ln && o[i] == nm[i]) i++;
+        if (i == ln) break;
+    }
+    slot_of[r] = (int32_t)at;
+    atomicMin(&gfirst[at], (uint32_t)r);
+    atomicAdd(&gcount[at], 1u);
+}
+
+__global__ __launch_bounds__(256) void mate_decide_kernel(int32_t n, MateInfo M, const uint32_t* gfirst, const uint32_t* gcount,
+                                                          const int32_t* slot_of) {
+    const int32_t z = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (z >= n) return;
+    const int32_t at = slot_of[z];
+    if (at < 0) return;
+    if (gcount[at] != 2u) {  // a name seen once (:350-370) or more than twice (:294-298)
+        mate_set_lone(M, z);
+        return;
+    }
+    const int32_t r = (int32_t)gfirst[at];
+    if (r == z) return;  // the pair is decided by its second record
+    const int32_t bfr = M.bam_flags[r], bfz = M.bam_flags[z];
+    bool ok = ((bfr & BF_FIRST_SEGMENT) && (bfz & BF_LAST_SEGMENT)) || ((bfz & BF_FIRST_SEGMENT) && (bfr & BF_LAST_SEGMENT));  // :320
+    int32_t t = 0;  // CramNormalizer.java:455-470
+    if (!(bfr & BF_UNMAPPED) && !(bfz & BF_UNMAPPED) && M.ref_id[r] == M.ref_id[z]) {
+        const int32_t p1 = (bfr & BF_REVERSE) ? M.aln_end[r] : M.aln_start[r];
+        const int32_t p2 = (bfz & BF_REVERSE) ? M.aln_end[z] : M.aln_start[z];
+        t = p2 - p1 + (p2 >= p1 ? 1 : -1);
+    }
+    ok = ok && M.tlen[r] == t && M.tlen[z] == -t;  // :323-336
+    ok = ok && M.mate_ref[r] == M.ref_id[z] && M.ref_id[r] == M.mate_ref[z] &&  // :341-346
+         ((M.mate_flags[r] & MF_NEG_STRAND) != 0) == ((bfz & BF_REVERSE) != 0) &&
+         ((M.mate_flags[z] & MF_NEG_STRAND) != 0) == ((bfr & BF_REVERSE) != 0) && M.mate_start[r] == M.aln_start[z] &&
+         M.mate_start[z] == M.aln_start[r];
+    if (!ok) {
+        mate_set_lone(M, r);
+        mate_set_lone(M, z);
+        return;
+    }
+    M.next_frag[r] = z - r - 1;  // :301-307; the second record's recordsToNextFragment is left as it is
+    M.comp_flags[r] = (M.comp_flags[r] | CRAMGPU_CF_HAS_MATE_DOWNSTREAM) & ~CRAMGPU_CF_DETACHED;
+    M.comp_flags[z] = M.comp_flags[z] & ~(CRAMGPU_CF_HAS_MATE_DOWNSTREAM | CRAMGPU_CF_DETACHED);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Slice content digests — htsjdk!cram/digest/ContentDigests as htsjdk!build/ContainerFactory#buildSlice drives it
+// (ContentDigests.create(ALL), add(record) per record, getAsTags() -> Slice.sliceTags).  BD / SD: java.util.zip.CRC32 of
+// every record's readBases / qualityScores (Crc32Hasher), the per-record values added as 32-bit integers
+// (IntegerSumCombine).  A thread per (record, series): CRC-32 (polynomial 0xEDB88320, the zlib one) byte by byte through
+// a table in LDS, then one atomic add per record into the slice's sum.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void content_crc_kernel(int32_t n, int32_t n_cont, const int32_t* cont_first,
+                                                          const int64_t* base_off, const int32_t* read_len, const uint8_t* bases,
+                                                          const uint8_t* quals, uint32_t* crc_sum) {
+    __shared__ uint32_t T[256];
+    {
+        uint32_t v = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v = (v >> 1) ^ (0xEDB88320u & (0u - (v & 1u)));
+        T[threadIdx.x] = v;
+    }
+    __syncthreads();
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t r = (int32_t)(id >> 1), which = (int32_t)(id & 1);
+    if (r >= n) return;
+    const uint8_t* p = (which ? quals : bases) + base_off[r];
+    const int32_t L = read_len[r];
+    uint32_t c = 0xFFFFFFFFu;
+    for (int32_t i = 0; i < L; i++) c = T[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    atomicAdd(&crc_sum[2 * (int64_t)cont_of(cont_first, n_cont, r) + which], ~c);
+}
+
 inline dim3 grid1(int64_t n, int per_block) { return dim3((unsigned)((n + per_block - 1) / per_block > 0 ? (n + per_block - 1) / per_block : 1)); }
 
 }  // namespace
@@ -642,6 +763,42 @@ hipError_t launch_restore_mates(int32_t n, int32_t n_cont, const int32_t* cont_f
                        serial, status);
     hipLaunchKernelGGL(mates_walk_kernel, grid1(n, 256), dim3(256), 0, s, n, n_cont, cont_first, c, aln_start, aln_end,
                        (const int32_t*)link, (const uint32_t*)nprev, (const uint8_t*)serial, (const int32_t*)status);
+    return hipGetLastError();
+}
+
+// ws: table[cap] | gfirst[cap] | gcount[cap] | slot_of[n], cap = mate_table_slots(n)
+size_t mate_table_slots(int32_t n) {
+    size_t cap = 1024;
+    while (cap < 2 * (size_t)(n > 0 ? n : 1)) cap <<= 1;
+    return cap;
+}
+hipError_t launch_set_mate_info(int32_t n, int32_t n_cont, const int32_t* cont_first, const cramgpu_record_cols& c,
+                                const int32_t* aln_start, const int32_t* aln_end, const uint8_t* names, const int64_t* name_off,
+                                const int32_t* name_len, int32_t* ws, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const size_t cap = mate_table_slots(n);
+    int32_t* table = ws;
+    uint32_t* gfirst = reinterpret_cast<uint32_t*>(ws + cap);
+    uint32_t* gcount = reinterpret_cast<uint32_t*>(ws + 2 * cap);
+    int32_t* slot_of = ws + 3 * cap;
+    hipError_t e = hipMemsetAsync(table, 0xFF, 2 * cap * sizeof(int32_t), s);  // table = -1, gfirst = 0xFFFFFFFF
+    if (e == hipSuccess) e = hipMemsetAsync(gcount, 0, cap * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const MateInfo M{c.bam_flags, c.ref_id,    aln_start, aln_end, c.mate_flags, c.mate_ref, c.mate_start,
+                     c.tlen,      c.comp_flags, c.next_frag, names, name_off,     name_len};
+    hipLaunchKernelGGL(mate_group_kernel, grid1(n, 256), dim3(256), 0, s, n, n_cont, cont_first, M, table, (uint32_t)(cap - 1),
+                       gfirst, gcount, slot_of);
+    hipLaunchKernelGGL(mate_decide_kernel, grid1(n, 256), dim3(256), 0, s, n, M, (const uint32_t*)gfirst, (const uint32_t*)gcount,
+                       (const int32_t*)slot_of);
+    return hipGetLastError();
+}
+
+hipError_t launch_content_crc(int32_t n, int32_t n_cont, const int32_t* cont_first, const int64_t* base_off, const int32_t* read_len,
+                              const uint8_t* bases, const uint8_t* quals, uint32_t* crc_sum, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(crc_sum, 0, 2 * (size_t)n_cont * sizeof(uint32_t), s);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(content_crc_kernel, grid1(2 * (int64_t)n, 256), dim3(256), 0, s, n, n_cont, cont_first, base_off, read_len,
+                       bases, quals, crc_sum);
     return hipGetLastError();
 }
 

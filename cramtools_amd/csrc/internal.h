@@ -100,6 +100,12 @@ hipError_t launch_cigars(int32_t n, const int32_t* read_len, const int32_t* aln_
 hipError_t launch_restore_mates(int32_t n, int32_t n_cont, const int32_t* cont_first, const cramgpu_record_cols& c,
                                 const int32_t* cont_ref_id, const int32_t* aln_start, const int32_t* aln_end, int32_t* link,
                                 uint32_t* nprev, uint8_t* serial, int32_t* status, hipStream_t s);
+size_t mate_table_slots(int32_t n);  // set_mate_info workspace: 3 * slots + n ints
+hipError_t launch_set_mate_info(int32_t n, int32_t n_cont, const int32_t* cont_first, const cramgpu_record_cols& c,
+                                const int32_t* aln_start, const int32_t* aln_end, const uint8_t* names, const int64_t* name_off,
+                                const int32_t* name_len, int32_t* ws, hipStream_t s);
+hipError_t launch_content_crc(int32_t n, int32_t n_cont, const int32_t* cont_first, const int64_t* base_off, const int32_t* read_len,
+                              const uint8_t* bases, const uint8_t* quals, uint32_t* crc_sum, hipStream_t s);
 hipError_t launch_bam_encode(int32_t n, const cramgpu_bam_cols& b, uint8_t* bam, int64_t cap, int64_t* rec_off, int32_t* status,
                              int32_t* d_sizes, int64_t* d_total, int64_t* d_scan_ws, hipStream_t s);
 hipError_t launch_bam_decode(int32_t n, const uint8_t* bam, const int64_t* rec_off, const cramgpu_bam_out& o, int32_t* status,

@@ -424,3 +424,137 @@ int64_t orc_bam_decode(int32_t n, const uint8_t* bam, const int64_t* rec_off, in
     }
     return nb;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * orc_set_mate_info: src/main/java/htsjdk/samtools/cram/CramSerilization.java:265-373 (detach, setMateInfo) for the records
+ * [first, last) of one container, statement by statement; the two TreeMap<String, record> of :275-276 are one
+ * open-addressing table keyed by (secondary?, name bytes) here (only get / put / values() are used: order-free).
+ * computeInsertSize: CramNormalizer.java:455-470.  comp_flags: bits 2 (detached) and 4 (mate downstream) are rewritten,
+ * the others kept.  next_frag: recordsToNextFragment (-1 where the reference sets -1).
+ * PARITY UNPINNED at the reference level (no fixture of the reference holds records after setMateInfo); the
+ * known-answer cases of tests/test_oracle_bam.py are worked by hand from the source.
+ * ------------------------------------------------------------------------------------------------------------------ */
+enum { BF_FIRST = 0x40, BF_LAST = 0x80, BF_SECONDARY = 0x100 };
+
+typedef struct {
+    const int32_t *bam_flags, *mate_flags, *ref_id, *aln_start, *aln_end, *mate_ref, *mate_start, *tlen;
+    int32_t *comp_flags, *next_frag, *next, *prev;
+    int32_t first;
+} MateCtx;
+
+static void mi_detach(const MateCtx* m, int32_t i) { /* :265-272 */
+    do {
+        m->comp_flags[m->first + i] = (m->comp_flags[m->first + i] | CF_DETACHED) & ~CF_MATE_DOWNSTREAM;
+        m->next_frag[m->first + i] = -1;
+    } while ((i = m->next[i]) >= 0);
+}
+static int32_t mi_insert_size(const MateCtx* m, int32_t a, int32_t z) { /* CramNormalizer.java:455-470 (a, z absolute) */
+    if ((m->bam_flags[a] & BF_UNMAPPED) || (m->bam_flags[z] & BF_UNMAPPED)) return 0;
+    if (m->ref_id[a] != m->ref_id[z]) return 0;
+    const int32_t p1 = (m->bam_flags[a] & BF_REVERSE) ? m->aln_end[a] : m->aln_start[a];
+    const int32_t p2 = (m->bam_flags[z] & BF_REVERSE) ? m->aln_end[z] : m->aln_start[z];
+    return p2 - p1 + (p2 >= p1 ? 1 : -1);
+}
+static uint64_t mi_hash(const uint8_t* s, int64_t n, int sec) {
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)sec;
+    for (int64_t i = 0; i < n; i++) h = (h ^ s[i]) * 1099511628211ull;
+    return h;
+}
+
+int32_t orc_set_mate_info(int32_t first, int32_t last, const int32_t* bam_flags, const int32_t* mate_flags, const int32_t* ref_id,
+                          const int32_t* aln_start, const int32_t* aln_end, const int32_t* mate_ref, const int32_t* mate_start,
+                          const int32_t* tlen, const uint8_t* names, const int64_t* name_off, int32_t* comp_flags,
+                          int32_t* next_frag) {
+    const int32_t n = last - first;
+    if (n <= 0) return 0;
+    size_t cap = 16;
+    while (cap < 2 * (size_t)n) cap <<= 1;
+    int32_t* table = (int32_t*)malloc(sizeof(int32_t) * cap); /* index of the record a (map, name) was put with, or -1 */
+    int32_t* next = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    int32_t* prev = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    for (size_t i = 0; i < cap; i++) table[i] = -1;
+    for (int32_t i = 0; i < n; i++) next[i] = prev[i] = -1;
+    MateCtx m = {bam_flags, mate_flags, ref_id, aln_start, aln_end, mate_ref, mate_start, tlen, comp_flags, next_frag, next, prev, first};
+#define SET_LONE(i) /* :279-284, :353-358 */                                                           \
+    do {                                                                                               \
+        comp_flags[first + (i)] = (comp_flags[first + (i)] | CF_DETACHED) & ~CF_MATE_DOWNSTREAM;       \
+        next_frag[first + (i)] = -1;                                                                   \
+        next[i] = prev[i] = -1;                                                                        \
+    } while (0)
+    for (int32_t i = 0; i < n; i++) { /* :277-310 */
+        const int32_t r = first + i;
+        if (!(bam_flags[r] & BF_PAIRED)) {
+            SET_LONE(i);
+            continue;
+        }
+        const int sec = (bam_flags[r] & BF_SECONDARY) ? 1 : 0;
+        const uint8_t* nm = names + name_off[r];
+        const int64_t ln = name_off[r + 1] - name_off[r];
+        size_t at = (size_t)mi_hash(nm, ln, sec) & (cap - 1);
+        int32_t mate = -1;
+        for (;; at = (at + 1) & (cap - 1)) {
+            const int32_t j = table[at];
+            if (j < 0) break;
+            const int32_t q = first + j;
+            if (((bam_flags[q] & BF_SECONDARY) ? 1 : 0) == sec && name_off[q + 1] - name_off[q] == ln &&
+                memcmp(names + name_off[q], nm, (size_t)ln) == 0) {
+                mate = j;
+                break;
+            }
+        }
+        if (mate < 0) {
+            table[at] = i; /* :291 */
+            continue;
+        }
+        int32_t p = mate;
+        if (next[p] >= 0 || prev[p] >= 0) { /* :294-298 */
+            mi_detach(&m, i);
+            mi_detach(&m, p);
+            continue;
+        }
+        while (next[p] >= 0) p = next[p];
+        next_frag[first + p] = i - p - 1; /* :301 (index difference) */
+        next[p] = i;
+        prev[i] = p;
+        comp_flags[first + p] = (comp_flags[first + p] | CF_MATE_DOWNSTREAM) & ~CF_DETACHED;
+        comp_flags[r] = comp_flags[r] & ~(CF_MATE_DOWNSTREAM | CF_DETACHED);
+    }
+    for (int32_t i = 0; i < n; i++) { /* :313-348 */
+        if (next[i] < 0 || prev[i] >= 0) continue;
+        const int32_t r = first + i;
+        int32_t l = i;
+        while (next[l] >= 0) l = next[l];
+        int32_t z = first + l;
+        if (((bam_flags[r] & BF_FIRST) && (bam_flags[z] & BF_LAST)) || ((bam_flags[z] & BF_FIRST) && (bam_flags[r] & BF_LAST))) {
+            const int32_t t = mi_insert_size(&m, r, z);
+            if (tlen[r] == t) {
+                l = next[i];
+                while (next[l] >= 0) {
+                    if (tlen[first + l] != -t) break;
+                    l = next[l];
+                }
+                if (tlen[first + l] != -t) mi_detach(&m, i);
+            } else {
+                mi_detach(&m, i);
+            }
+        } else {
+            mi_detach(&m, i);
+        }
+        z = first + l;
+        if (mate_ref[r] != ref_id[z] || ref_id[r] != mate_ref[z] ||
+            ((mate_flags[r] & MF_NEG_STRAND) != 0) != ((bam_flags[z] & BF_REVERSE) != 0) ||
+            ((mate_flags[z] & MF_NEG_STRAND) != 0) != ((bam_flags[r] & BF_REVERSE) != 0) || mate_start[r] != aln_start[z] ||
+            mate_start[z] != aln_start[r])
+            mi_detach(&m, i);
+    }
+    for (size_t s = 0; s < cap; s++) { /* :350-370: the values of both maps */
+        const int32_t i = table[s];
+        if (i < 0 || next[i] >= 0) continue;
+        SET_LONE(i);
+    }
+#undef SET_LONE
+    free(table);
+    free(next);
+    free(prev);
+    return 0;
+}

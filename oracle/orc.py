@@ -487,6 +487,38 @@ def restore_mates(cont_first, cols, ref_id, aln_start, aln_end):
     return out, status
 
 
+def set_mate_info(cont_first, cols, ref_id, aln_start, aln_end, names, name_off):
+    """CramSerilization.java:274-373 per container.  cols: dict with bam_flags, comp_flags, next_frag, mate_flags, mate_ref,
+    mate_start, tlen; names: bytes back to back, name_off[n + 1].  -> (comp_flags, next_frag) copies after the call."""
+    i32 = lambda x: _a(x, np.int32)
+    cf, nf = i32(cols["comp_flags"]).copy(), i32(cols["next_frag"]).copy()
+    bf, mf, rid, st, en = i32(cols["bam_flags"]), i32(cols["mate_flags"]), i32(ref_id), i32(aln_start), i32(aln_end)
+    mr, ms, tl = i32(cols["mate_ref"]), i32(cols["mate_start"]), i32(cols["tlen"])
+    nm, no = _a(np.frombuffer(bytes(names), np.uint8) if not isinstance(names, np.ndarray) else names, np.uint8), _a(name_off, np.int64)
+    if nm.size == 0:
+        nm = np.zeros(1, np.uint8)
+    for c in range(len(cont_first) - 1):
+        lib().orc_set_mate_info(ctypes.c_int32(int(cont_first[c])), ctypes.c_int32(int(cont_first[c + 1])), _p(bf), _p(mf), _p(rid),
+                                _p(st), _p(en), _p(mr), _p(ms), _p(tl), _p(nm), _p(no), _p(cf), _p(nf))
+    return cf, nf
+
+
+def content_digests(cont_first, base_off, read_len, bases, quals):
+    """ContentDigests BD / SD (htsjdk 2.4.1 cram/digest, bytecode only: Crc32Hasher + IntegerSumCombine) per container, with
+    zlib's CRC-32 — the function java.util.zip.CRC32 wraps.  -> uint32 [n_cont, 2].  TEST INFRASTRUCTURE."""
+    import zlib
+    b, q = bytes(_u8(bases)), bytes(_u8(quals))
+    out = np.zeros((len(cont_first) - 1, 2), np.uint32)
+    for c in range(len(cont_first) - 1):
+        bd = sd = 0
+        for r in range(int(cont_first[c]), int(cont_first[c + 1])):
+            o, L = int(base_off[r]), int(read_len[r])
+            bd = (bd + zlib.crc32(b[o:o + L])) & 0xFFFFFFFF
+            sd = (sd + zlib.crc32(q[o:o + L])) & 0xFFFFFFFF
+        out[c] = (bd, sd)
+    return out
+
+
 def bam_encode(ref_id, aln_start, aln_end, mapq, bam_flags, mate_flags, mate_ref, mate_start, tlen, read_len, base_off, bases,
                quals, has_quals, n_cigar, cigar_off, cigar, names=None, name_off=None, name_base=0, tags=None, tag_off=None,
                cap=None):

@@ -89,3 +89,98 @@ def random_batch(rng, sizes, max_len=60):
 def sc_cols():
     return ("bam_flags", "comp_flags", "ref_id", "read_group", "mate_flags", "mate_ref", "mate_start", "tlen", "next_frag",
             "tag_list")
+
+
+def insert_size(bf, ref, start, end, a, z):
+    """CramNormalizer.java:455-470 in plain Python (records a, z)."""
+    if (bf[a] & 4) or (bf[z] & 4) or ref[a] != ref[z]:
+        return 0
+    p1 = end[a] if bf[a] & 16 else start[a]
+    p2 = end[z] if bf[z] & 16 else start[z]
+    return p2 - p1 + (1 if p2 >= p1 else -1)
+
+
+def mate_batch(rng, sizes):
+    """Containers of records as Sam2CramRecordFactory leaves them before setMateInfo (CramSerilization.java:274-373):
+    templates of one record (paired or not), proper pairs (every field consistent), pairs with one field off, templates of
+    three and four records, secondary alignments that share the name of a primary pair; the records of a container in
+    random order; the same names in every container; names of different lengths that share prefixes."""
+    cols = {k: [] for k in sc_cols()}
+    names, start, end, ref = [], [], [], []
+    want_kind = []
+    for ci, n in enumerate(sizes):
+        recs = []  # (template id, kind)
+        t = 0
+        while len(recs) < n:
+            room = n - len(recs)
+            k = rng.choice(["single", "lone", "pair", "pair", "pair", "bad", "three", "four", "sec"])
+            need = dict(single=1, lone=1, pair=2, bad=2, three=3, four=4, sec=4)[k]
+            if need > room:
+                k, need = "lone", 1
+            recs += [(t, k, j) for j in range(need)]
+            t += 1
+        order = rng.permutation(len(recs))
+        recs = [recs[i] for i in order]
+        base = len(names)
+        for (tid, k, j) in recs:
+            names.append(("t%d" % tid).encode() * (1 + tid % 3) + (b"/x" if tid % 5 == 0 else b""))
+            paired = k != "single"
+            bf = (1 if paired else 0) | (16 if rng.random() < 0.5 else 0) | (4 if rng.random() < 0.05 else 0)
+            if k == "sec" and j >= 2:
+                bf |= 0x100
+            cols["bam_flags"].append(bf)
+            cols["comp_flags"].append(int(rng.integers(0, 16)))
+            cols["next_frag"].append(int(rng.integers(-1, 5)))
+            cols["ref_id"].append(int(rng.integers(0, 3)) if rng.random() < 0.2 else 1)
+            s = int(rng.integers(1, 5000))
+            start.append(s)
+            end.append(s + int(rng.integers(0, 200)))
+            ref.append(cols["ref_id"][-1])
+            for c in ("mate_flags", "mate_ref", "mate_start", "tlen"):
+                cols[c].append(int(rng.integers(0, 3)))
+            cols["read_group"].append(0)
+            cols["tag_list"].append(0)
+        # make the two-record templates consistent in container order, then spoil the "bad" ones
+        groups = {}
+        for i, (tid, k, j) in enumerate(recs):
+            groups.setdefault((tid, bool(cols["bam_flags"][base + i] & 0x100)), []).append(base + i)
+        for (tid, sec), idx in groups.items():
+            kind = recs[idx[0] - base][1]
+            if len(idx) != 2 or kind == "single":
+                continue
+            a, z = idx
+            fl = (0x40, 0x80) if rng.random() < 0.5 else (0x80, 0x40)
+            cols["bam_flags"][a] |= fl[0]
+            cols["bam_flags"][z] |= fl[1]
+            bfv = cols["bam_flags"]
+            tl = insert_size(bfv, ref, start, end, a, z)
+            cols["tlen"][a], cols["tlen"][z] = tl, -tl
+            cols["mate_ref"][a], cols["mate_ref"][z] = ref[z], ref[a]
+            cols["mate_start"][a], cols["mate_start"][z] = start[z], start[a]
+            cols["mate_flags"][a] = (2 if rng.random() < 0.3 else 0) | (1 if bfv[z] & 16 else 0)
+            cols["mate_flags"][z] = (2 if rng.random() < 0.3 else 0) | (1 if bfv[a] & 16 else 0)
+            if kind == "bad":
+                w = int(rng.integers(0, 7))
+                e = a if rng.random() < 0.5 else z
+                if w == 0:
+                    cols["tlen"][e] += 1
+                elif w == 1:
+                    cols["mate_start"][e] += 1
+                elif w == 2:
+                    cols["mate_ref"][e] += 1
+                elif w == 3:
+                    cols["mate_flags"][e] ^= 1
+                elif w == 4:
+                    cols["bam_flags"][a] &= ~0xC0  # neither first nor last
+                elif w == 5:
+                    cols["bam_flags"][z] = (cols["bam_flags"][z] & ~0xC0) | (cols["bam_flags"][a] & 0xC0)  # both the same end
+                else:
+                    cols["tlen"][a], cols["tlen"][z] = cols["tlen"][z], cols["tlen"][a]
+                    if cols["tlen"][a] == 0:
+                        cols["tlen"][a] = 5
+        want_kind += [r[1] for r in recs]
+    cols = {k: np.asarray(v, np.int32) for k, v in cols.items()}
+    name_off = np.concatenate([[0], np.cumsum([len(x) for x in names])]).astype(np.int64)
+    return dict(n=len(names), cont_first=np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), cols=cols,
+                aln_start=np.asarray(start, np.int32), aln_end=np.asarray(end, np.int32),
+                names=np.frombuffer(b"".join(names) + b"\0", np.uint8), name_off=name_off, kind=want_kind)

@@ -234,3 +234,72 @@ def test_mates_and_cigars_at_scale(orc):
         assert (want_m["tlen"] != 5).sum() > n // 4  # the chains really were restored
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed,sizes", [(0, [1]), (1, [2, 3]), (2, [700, 5, 256, 257]), (3, [10000, 10000, 4000])])
+def test_set_mate_info_matches_oracle(orc, seed, sizes):
+    """cramgpu_set_mate_info_dev against the sequential restatement of CramSerilization.java:274-373: names scattered in a
+    buffer (offset + length, as cramgpu_bam_decode_dev reports them), every template kind of bam_cases.mate_batch."""
+    from cramtools_amd import bam, records, external_compression as xc
+    import torch
+    rng = np.random.default_rng(300 + seed)
+    b = bc.mate_batch(rng, sizes)
+    c = b["cols"]
+    want_cf, want_nf = orc.set_mate_info(b["cont_first"], c, c["ref_id"], b["aln_start"], b["aln_end"], b["names"], b["name_off"])
+    # the names as a BAM stripe holds them: not back to back, in another order
+    n = b["n"]
+    lens = np.diff(b["name_off"]).astype(np.int32)
+    perm = rng.permutation(n)
+    gaps = rng.integers(1, 40, n)
+    pos = np.zeros(n, np.int64)
+    at = 0
+    for r in perm:
+        at += int(gaps[r])
+        pos[r] = at
+        at += int(lens[r])
+    buf = rng.integers(0, 256, at + 8).astype(np.uint8)
+    for r in range(n):
+        buf[pos[r]:pos[r] + lens[r]] = b["names"][b["name_off"][r]:b["name_off"][r + 1]]
+    eng = xc.Engine(0)
+    try:
+        cols = records.RecordColumns(DEV, n, **c)
+        ser = bam.CramSerilization(eng, DEV)
+        ser.set_mate_info(cols, _t(b["cont_first"]), _t(b["aln_start"]), _t(b["aln_end"]), _t(buf), _t(pos), _t(lens))
+        torch.cuda.synchronize()
+        assert np.array_equal(cols.comp_flags.cpu().numpy(), want_cf)
+        assert np.array_equal(cols.next_frag.cpu().numpy(), want_nf)
+        for k in ("bam_flags", "mate_flags", "mate_ref", "mate_start", "tlen", "ref_id"):
+            assert np.array_equal(getattr(cols, k).cpu().numpy(), c[k]), k
+        # a second call on its own output changes nothing (the links are a function of the names and the mate fields)
+        ser.set_mate_info(cols, _t(b["cont_first"]), _t(b["aln_start"]), _t(b["aln_end"]), _t(buf), _t(pos), _t(lens))
+        torch.cuda.synchronize()
+        assert np.array_equal(cols.comp_flags.cpu().numpy(), want_cf)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("seed,sizes,max_len", [(0, [1, 0, 3], 60), (1, [700, 256], 300), (2, [40], 20000)])
+def test_content_digests_match_oracle(orc, seed, sizes, max_len):
+    from cramtools_amd import bam, external_compression as xc
+    import torch
+    rng = np.random.default_rng(400 + seed)
+    n = sum(sizes)
+    read_len = rng.integers(0, max_len + 1, n).astype(np.int32)
+    base_off = np.concatenate([[0], np.cumsum(read_len)]).astype(np.int64)
+    bases = rng.integers(0, 256, int(base_off[-1]) + 16).astype(np.uint8)
+    quals = rng.integers(0, 94, int(base_off[-1]) + 16).astype(np.uint8)
+    cont_first = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    want = orc.content_digests(cont_first, base_off, read_len, bases, quals)
+    eng = xc.Engine(0)
+    try:
+        ser = bam.CramSerilization(eng, DEV)
+        got = ser.content_digests(_t(cont_first), _t(base_off), _t(read_len), _t(bases), _t(quals))
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy().astype(np.uint32), want)
+        tags = bam.slice_content_tags(int(got[0, 0]), int(got[0, 1]))
+        import hashlib
+        assert [t for t, _ in tags] == ["BD", "SD", "B5", "S5", "B1", "S1"]
+        assert tags[0][1] == int(want[0, 0]).to_bytes(4, "little") and tags[2][1] == hashlib.sha512(b"").digest()
+        assert tags[5][1] == hashlib.sha1(b"").digest()
+    finally:
+        eng.close()

@@ -170,6 +170,10 @@ def test_bam_test_bodies(hostsim, orc, monkeypatch):
     t.test_assembly_and_encode_match_oracle(orc, 2, [300, 5, 257])
     t.test_decoder_flags_malformed_records(orc)
     t.test_slice_md5_matches_hashlib(orc)
+    t.test_set_mate_info_matches_oracle(orc, 1, [2, 3])
+    t.test_set_mate_info_matches_oracle(orc, 2, [700, 5, 256, 257])
+    t.test_content_digests_match_oracle(orc, 0, [1, 0, 3], 60)
+    t.test_content_digests_match_oracle(orc, 1, [700, 256], 300)
 
 
 def test_gunzip_test_bodies(hostsim, monkeypatch):

@@ -170,3 +170,63 @@ def test_mates_random_chains_are_consistent(orc):
     assert set(st.tolist()) <= {0, -9}
     linked = ((c["bam_flags"] & 1) != 0) & ((c["comp_flags"] & 2) == 0)
     assert (out["next_frag"][~linked] == -1).all()
+
+
+def test_set_mate_info_known_answers(orc):
+    """CramSerilization.java:274-373 worked by hand.  Records (name, flags):
+    0 a 0x41 fwd  + 1 a 0x91 rev: a proper pair (template 399 - 100 + 1 = 300)      -> 0: mate downstream, NF 0; 1: neither bit
+    2 b 0x00 not multi-fragment                                                     -> detached (:278-284)
+    3 c 0x41 name seen once                                                         -> detached (:350-358)
+    4 d 0x41 + 6 d 0x91: template size of 4 off by one                              -> both detached (:334-336)
+    5 e, 7 e, 8 e: a third record of the name                                        -> all detached (:294-298)
+    9 a 0x141 secondary: its own map (:287), alone there                             -> detached, pair 0/1 untouched
+    10 f 0x41 + 13 f 0x81 fwd/fwd, 13 in front of 10: template -(2000 - 1500) - 1   -> 10: mate downstream, NF 2
+    11 g 0x41 + 12 g 0x81: mate start of 12 does not name 11's start                 -> both detached (:341-346)"""
+    names = [b"a", b"a", b"b", b"c", b"d", b"e", b"d", b"e", b"e", b"a", b"f", b"g", b"g", b"f"]
+    bf = [0x41, 0x91, 0x00, 0x41, 0x41, 0x41, 0x91, 0x81, 0x41, 0x141, 0x41, 0x41, 0x81, 0x81]
+    start = [100, 300, 10, 20, 100, 700, 300, 800, 900, 100, 2000, 50, 60, 1500]
+    end = [199, 399, 19, 29, 199, 799, 399, 899, 999, 199, 2099, 149, 159, 1599]
+    n = len(names)
+    mate_start = [300, 100, 0, 0, 300, 0, 100, 0, 0, 300, 1500, 60, 51, 2000]
+    mate_flags = [1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0]
+    tlen = [300, -300, 0, 0, 301, 0, -300, 0, 0, 300, -501, 11, -11, 501]
+    cols = _cols(n, bam_flags=bf, comp_flags=[3, 3, 1, 0, 6, 0, 0, 4, 0, 0, 2, 0, 0, 7], next_frag=[9] * n, mate_start=mate_start,
+                 mate_flags=mate_flags, tlen=tlen, mate_ref=[0] * n)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in names])])
+    cf, nf = orc.set_mate_info([0, n], cols, [0] * n, start, end, b"".join(names), off)
+    D, MD = 2, 4
+    assert cf.tolist() == [1 | MD, 1, 1 | D, D, D, D, D, D, D, D, MD, D, D, 1]
+    assert nf.tolist() == [0, 9, -1, -1, -1, -1, -1, -1, -1, -1, 2, -1, -1, 9]
+    # the same records as two containers: names do not link across the boundary (each container has its own maps)
+    cf2, nf2 = orc.set_mate_info([0, 1, n], cols, [0] * n, start, end, b"".join(names), off)
+    assert cf2[0] == 1 | D and cf2[1] == 1 | D and nf2[0] == -1 and cf2.tolist()[2:] == cf.tolist()[2:]
+
+
+def test_set_mate_info_random_batches_follow_their_construction(orc):
+    rng = np.random.default_rng(77)
+    b = bc.mate_batch(rng, [1, 2, 60, 500])
+    c = b["cols"]
+    cf, nf = orc.set_mate_info(b["cont_first"], c, c["ref_id"], b["aln_start"], b["aln_end"], b["names"], b["name_off"])
+    for r, k in enumerate(b["kind"]):
+        if k in ("single", "lone", "bad", "three", "four"):
+            assert cf[r] & 2 and not cf[r] & 4 and nf[r] == -1, (r, k)
+            assert (cf[r] & ~6) == (c["comp_flags"][r] & ~6)
+        else:  # pair / sec: one record of the two has the mate downstream, neither is detached
+            assert not cf[r] & 2, (r, k)
+    md = np.flatnonzero(cf & 4)
+    assert len(md) == sum(k in ("pair", "sec") for k in b["kind"]) // 2
+    for r in md:  # the distance names the record of the same name
+        z = r + 1 + nf[r]
+        nm = lambda i: bytes(b["names"][b["name_off"][i]:b["name_off"][i + 1]])
+        assert nm(r) == nm(z) and (c["bam_flags"][r] & 0x100) == (c["bam_flags"][z] & 0x100)
+
+
+def test_content_digests_known_answers(orc):
+    """CRC-32 check value (ISO 3309 / zlib): crc32("123456789") = 0xCBF43926; the sum wraps at 32 bits."""
+    bases = np.frombuffer(b"123456789" + b"123456789" + b"ACGT", np.uint8)
+    quals = np.frombuffer(b"!" * 9 + b"123456789" + b"IIII", np.uint8)
+    out = orc.content_digests([0, 2, 3, 3], [0, 9, 18], [9, 9, 4], bases, quals)
+    import zlib
+    assert out[0, 0] == (2 * 0xCBF43926) & 0xFFFFFFFF
+    assert out[0, 1] == (zlib.crc32(b"!" * 9) + 0xCBF43926) & 0xFFFFFFFF
+    assert out[1, 0] == zlib.crc32(b"ACGT") and out[2].tolist() == [0, 0]
