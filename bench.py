@@ -28,6 +28,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Hardware queues of this process (read by the HIP runtime at its first call): launches of streams that share a queue
+# serialise, and the decode leg (K2 beside gunzip), the job slots and the coalescing queue overlap launches of several
+# streams.  HIP's default of 4 leaves three for them (scripts/ubench/streams_concurrency.py); the bench asks for 8,
+# as INTEGRATION.md tells a JVM host to, and reports it (`hw_queues`).  BENCH_HW_QUEUES overrides.
+HW_QUEUES = max(1, min(32, int(os.environ.get("BENCH_HW_QUEUES", "8"))))
+os.environ["GPU_MAX_HW_QUEUES"] = str(HW_QUEUES)
+
 import numpy as np
 import torch
 
@@ -757,6 +764,134 @@ def pcie_inclusive(eng, w, per_job=256, n_cont=None, outstanding=4, reps=2, pack
                 note="raw blocks from pinned host arenas, streams back into pinned host arenas (H2D + kernels + D2H)")
 
 
+def pcie_coalesced(eng, w, n_cont=None, threads=(), tickets=(64, 128), max_batches=0, reps=2):
+    """PCIe-inclusive rate of the coalescing queue at the reference's own job size — ONE container per submission
+    (paralell/TransformerJob.java:29-41): raw blocks in pinned host arenas -> packed streams in pinned host arenas.
+    `threads`: T worker threads that call the blocking cramgpu_rans_coalesced in a loop (the Java thread model);
+    `tickets`: one thread keeps W tickets outstanding (cramgpu_rans_enqueue / cramgpu_ticket_wait).  Every stream's
+    header is checked against its block.  Returns one dict per case.  Never the headline `value`."""
+    import threading
+    L = _lib.lib()
+    ns = len(SERIES)
+    n_cont = min(n_cont or w["n_cont"], w["n_cont"])
+    d_in = w["d_in"]
+    conts = []
+    for k in range(n_cont):
+        idx = range(k * ns, (k + 1) * ns)
+        lens = [w["blocks"][i].in_len for i in idx]
+        orders = [w["blocks"][i].order for i in idx]
+        blocks, in_bytes, out_bytes = xc.Engine.plan_encode(lens, orders)
+        h_in, h_out = L.cramgpu_host_alloc(in_bytes), L.cramgpu_host_alloc(out_bytes)
+        h_len, h_pos = L.cramgpu_host_alloc(4 * ns), L.cramgpu_host_alloc(8 * (ns + 1))
+        assert h_in and h_out and h_len and h_pos, "cramgpu_host_alloc failed"
+        arena = torch.from_numpy(np.ctypeslib.as_array(C.cast(h_in, C.POINTER(C.c_uint8)), shape=(in_bytes,)))
+        b0, bl = w["blocks"][idx[0]], w["blocks"][idx[-1]]
+        arena[:bl.in_off - b0.in_off + bl.in_len] = d_in[b0.in_off:bl.in_off + bl.in_len].cpu()
+        conts.append((blocks, in_bytes, out_bytes, h_in, h_out, h_len, h_pos, sum(lens)))
+    raw = sum(c[-1] for c in conts)
+    q = L.cramgpu_coalescer_open(eng.handle, max_batches)
+    assert q, _lib.last_error()
+
+    def call_args(c):
+        blocks, in_bytes, out_bytes, h_in, h_out, h_len, h_pos, _ = c
+        return (q, 0, h_in, in_bytes, h_out, out_bytes, C.addressof(blocks), ns, h_len, h_pos)
+
+    def check(c, k):
+        blocks, _, _, _, h_out, h_len, h_pos, _ = c
+        lens = np.ctypeslib.as_array(C.cast(h_len, C.POINTER(C.c_int32)), shape=(ns,))
+        pos = np.ctypeslib.as_array(C.cast(h_pos, C.POINTER(C.c_int64)), shape=(ns + 1,))
+        out = np.ctypeslib.as_array(C.cast(h_out, C.POINTER(C.c_uint8)), shape=(int(pos[ns]),))
+        assert (lens > 9).all(), (k, lens)
+        for i in range(ns):
+            head = bytes(out[int(pos[i]):int(pos[i]) + 9])
+            assert head[0] == blocks[i].order and int.from_bytes(head[5:9], "little") == blocks[i].in_len, (k, i)
+            assert int.from_bytes(head[1:5], "little") + 9 == lens[i], (k, i)
+        return int(lens.sum())
+
+    # worker threads: native ones (scripts/ubench/libco_driver.so, built by __graft_entry__.build) so that the figure
+    # is the library's and not the interpreter lock's; Python threads when the helper is missing
+    drv_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "ubench", "libco_driver.so")
+    drv = C.CDLL(drv_path) if os.path.exists(drv_path) else None
+    if drv is not None:
+        drv.co_driver_threads.restype = C.c_double
+        PP = C.c_void_p * n_cont
+        I64A = C.c_int64 * n_cont
+        arr = dict(h_in=PP(*[c[3] for c in conts]), in_bytes=I64A(*[c[1] for c in conts]), h_out=PP(*[c[4] for c in conts]),
+                   out_bytes=I64A(*[c[2] for c in conts]), blocks=PP(*[C.addressof(c[0]) for c in conts]),
+                   h_len=PP(*[c[5] for c in conts]), h_pos=PP(*[c[6] for c in conts]))
+
+    def threads_run(T):
+        if drv is not None:
+            err = C.c_int32(0)
+            dt = drv.co_driver_threads(C.cast(L.cramgpu_rans_coalesced, C.c_void_p), C.c_void_p(q), C.c_int32(n_cont), C.c_int32(T),
+                                       arr["h_in"], arr["in_bytes"], arr["h_out"], arr["out_bytes"], arr["blocks"], C.c_int32(ns),
+                                       arr["h_len"], arr["h_pos"], C.byref(err))
+            assert err.value == 0, (err.value, _lib.last_error())
+            return dt
+        nxt, lock, errs = [0], threading.Lock(), []
+
+        def worker():
+            while True:
+                with lock:
+                    k = nxt[0]
+                    nxt[0] += 1
+                if k >= n_cont:
+                    return
+                rc = L.cramgpu_rans_coalesced(*call_args(conts[k]))
+                if rc:
+                    errs.append((k, rc, _lib.last_error()))
+                    return
+
+        ths = [threading.Thread(target=worker) for _ in range(T)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        assert not errs, errs[:3]
+        return dt
+
+    def window_run(W):
+        pend = []
+        t0 = time.perf_counter()
+        for c in conts:
+            if len(pend) == W:
+                _lib.check(L.cramgpu_ticket_wait(q, pend.pop(0)))
+            t = L.cramgpu_rans_enqueue(*call_args(c))
+            assert t > 0, _lib.last_error()
+            pend.append(t)
+        for t in pend:
+            _lib.check(L.cramgpu_ticket_wait(q, t))
+        return time.perf_counter() - t0
+
+    def stats():
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(L.cramgpu_coalesce_stats(q, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value
+
+    window_run(64)  # warm-up: the batch slots grow to their working size
+    res = []
+    for mode, counts in (("threads", threads), ("tickets", tickets)):
+        for n in counts:
+            s0 = stats()
+            dt = min((threads_run if mode == "threads" else window_run)(n) for _ in range(reps))
+            s1 = stats()
+            comp = sum(check(c, k) for k, c in enumerate(conts))
+            res.append(dict(value=raw / dt / 1e6, unit="MB/s",
+                            entry_point="cramgpu_rans_coalesced" if mode == "threads" else "cramgpu_rans_enqueue",
+                            containers_per_submission=1, outstanding=n,
+                            driver=("native threads" if drv is not None else "python threads") if mode == "threads" else mode,
+                            containers=n_cont, ms=dt * 1e3,
+                            raw_MB=raw / 1e6, compressed_MB=comp / 1e6,
+                            containers_per_launch=(s1[1] - s0[1]) / max(1, s1[0] - s0[0])))
+    L.cramgpu_coalescer_close(q)
+    for c in conts:
+        for p in c[3:7]:
+            L.cramgpu_host_free(p)
+    return res
+
+
 # ======================================================================================================
 # --config 4: BASELINE.json configs[4] (10 kbp reads, high indel rate, lossy model R8-N40-D8, order-1 rANS) as one timed
 # pipeline.  Not the headline (that stays configs[1]); here so that the config's number is reproducible.
@@ -1018,6 +1153,9 @@ class GpuBackend:
     def pcie(self, w):
         return pcie_inclusive(self.eng, w)
 
+    def pcie_coalesced(self, w):
+        return pcie_coalesced(self.eng, w, threads=(64,), tickets=(64, 128))
+
     def close(self):
         self.eng.close()
 
@@ -1134,6 +1272,9 @@ def main(argv=None, backend_factory=GpuBackend):
                     extra["decode"]["assembly"]["bgzf"] = bgzf_image(dec)
         if not a.no_pcie and world == 1:
             extra["pcie_inclusive"] = be.pcie(w)
+            extra["pcie_inclusive"]["hw_queues"] = HW_QUEUES
+            if hasattr(be, "pcie_coalesced"):
+                extra["pcie_inclusive"]["one_container_per_submission"] = be.pcie_coalesced(w)
         total_raw = w["raw_bytes"] * world
         line = dict(metric="CRAM encode hot path: uncompressed external-block payload MB/s (rANS o0/o1 + feature extraction)",
                     value=total_raw * a.steps / dt / 1e6, unit="MB/s", n_gpus=world, steps=a.steps, warmup=a.warmup,

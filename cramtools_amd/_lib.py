@@ -151,6 +151,13 @@ SYMBOLS = {
     "cramgpu_rans_submit_packed": (P, [P, P, I64, P, I64, P, I32, P, P]),
     "cramgpu_job_poll": (I32, [P]),
     "cramgpu_job_wait": (I32, [P]),
+    "cramgpu_coalescer_open": (P, [P, I32]),
+    "cramgpu_coalescer_close": (None, [P]),
+    "cramgpu_rans_enqueue": (I64, [P, I32, P, I64, P, I64, P, I32, P, P]),
+    "cramgpu_ticket_poll": (I32, [P, I64]),
+    "cramgpu_ticket_wait": (I32, [P, I64]),
+    "cramgpu_rans_coalesced": (I32, [P, I32, P, I64, P, I64, P, I32, P, P]),
+    "cramgpu_coalesce_stats": (I32, [P, P, P, P]),
     "cramgpu_extract_features_dev": (I64, [P, P, P, P, P, P]),
     "cramgpu_substitution_matrix": (None, [P, P]),
     "cramgpu_assign_codes_dev": (I32, [P, I32, P, I32, P, P, P]),

@@ -2,12 +2,17 @@
 // There is deliberately no CPU implementation of any kernel here: without a gfx950 device every compute entry
 // point fails with CRAMGPU_E_NO_DEVICE / CRAMGPU_E_HIP.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "internal.h"
@@ -25,6 +30,12 @@ constexpr size_t kStaticBytes = kStaticGsOff + (size_t)kStaticGroups * ENC_GSCRA
 static __device__ __align__(256) uint8_t scratch[kStaticBytes];
 
 namespace {
+
+// Hardware queues of the process: HIP spreads streams over GPU_MAX_HW_QUEUES queues (its default: 4) round robin and
+// launches of streams that share a queue serialise; the job slots and the coalescing queue overlap launches of several
+// streams (each lasts one chain latency however small it is).  Asked for when the library is loaded, which in a JNI
+// host (System.loadLibrary) is before the first HIP call initialises the runtime; an explicit setting wins.
+__attribute__((constructor)) void process_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 thread_local std::string g_err;
 
@@ -49,16 +60,26 @@ int env_int(const char* name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 
+// hipFree / hipHostFree wait for the whole device.  A thread that must not stall while other launches are in flight (the
+// coalescing queue's dispatcher) points this at a list: buffers it outgrows are parked there instead of freed, and grow
+// geometrically so that the list stays short; the owner of the list frees it when nothing is in flight.
+struct Graveyard {
+    std::vector<void*> dev, pin;
+};
+thread_local Graveyard* tl_graveyard = nullptr;
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;  // elements
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p && tl_graveyard) tl_graveyard->dev.push_back(p);
+        else if (p) (void)hipFree(p);
         p = nullptr;
-        cap = 0;
         size_t want = std::max(n, (size_t)1024);
+        if (tl_graveyard) want = std::max(want, 2 * cap);
+        cap = 0;
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
         if (e == hipSuccess) cap = want;
         return e;
@@ -75,10 +96,12 @@ struct PinBuf {
     size_t cap = 0;
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
+        if (p && tl_graveyard) tl_graveyard->pin.push_back(p);
+        else if (p) (void)hipHostFree(p);
         p = nullptr;
-        cap = 0;
         size_t want = std::max(n, (size_t)1024);
+        if (tl_graveyard) want = std::max(want, 2 * cap);
+        cap = 0;
         hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
         if (e == hipSuccess) cap = want;
         return e;
@@ -868,6 +891,441 @@ int32_t cramgpu_job_wait(cramgpu_job* j) {
     }
     j->busy = false;  // the slot (and its device buffers) can take the next submission
     return rc;
+}
+
+}  // extern "C"
+
+// ---- coalescing queue: one container per call, many calls at once ----
+// The reference hands ONE container to a worker thread (paralell/TransformerJob.java:29-41 runs a
+// BamToCram_OBA_Function / CramToBam_OBA_Function per stripe; CRAMContainerAsynchWriter.java:139-149 a Batch per
+// container).  A launch per container costs one chain latency (the container's longest block, ~8 ms for 1.5 MB of
+// scores) whatever else the GPU could do meanwhile, so the library commits in groups: submissions queue up, a dispatcher
+// thread turns EVERYTHING that is waiting into one launch the moment a batch slot is free, a completer thread brings
+// the results back and wakes the callers.  Under load a batch holds all the containers that arrived during the previous
+// batch's latency; alone, a submission starts at once.
+struct CoSub {
+    int64_t id = 0;
+    bool decode = false, packed = false;
+    const uint8_t* in = nullptr;
+    uint8_t* out = nullptr;
+    int64_t in_bytes = 0, out_bytes = 0;
+    std::vector<cramgpu_block> blocks;
+    int32_t* out_len = nullptr;
+    int64_t* out_pos = nullptr;
+    int state = 0;  // 0 queued, 1 in a batch, 2 finished
+    std::chrono::steady_clock::time_point arrived;
+    int32_t rc = 0;
+    std::string err;
+    int64_t in_base = 0, out_base = 0, lo = 0, hi = 0, max_cap = 0;
+    int32_t first = 0;
+};
+
+struct CoBatch {
+    LaunchRes res;
+    hipStream_t stream = nullptr;
+    hipEvent_t uploaded = nullptr, coded = nullptr, done = nullptr;
+    DevBuf<uint8_t> d_in, d_out, d_pack;
+    DevBuf<int32_t> d_len, d_err;
+    DevBuf<int64_t> d_pos, d_off;
+    PinBuf<int32_t> h_len;
+    PinBuf<int64_t> h_pos;
+    std::vector<CoSub*> subs;
+    std::vector<cramgpu_block> blocks;
+    bool decode = false;
+    int phase = 0;  // 1 launched (waiting for `coded`), 2 results on their way to the callers' arenas (waiting for `done`)
+    double t_pick = 0, t_issued = 0, t_coded = 0;  // CRAMGPU_COALESCE_TRACE=1
+};
+
+struct cramgpu_coalescer {
+    cramgpu_ctx* ctx = nullptr;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_flight, cv_done;
+    std::deque<CoSub*> queue;
+    std::unordered_map<int64_t, CoSub*> tickets;
+    std::vector<CoBatch> batches;
+    std::vector<CoBatch*> free_batches;
+    std::deque<CoBatch*> inflight;
+    hipStream_t upload_stream = nullptr;
+    std::thread dispatcher, completer;
+    int64_t next_id = 1;
+    bool stop = false;
+    // what one batch may hold: bounds the device arenas of a batch slot
+    int64_t max_in_bytes = 0;
+    int32_t max_subs = 0;
+    // While other batches are in flight a lone arrival is held back this long for company: callers woken by one batch
+    // come back within a fraction of a millisecond of each other, and a launch of one container ties up a stream (the
+    // hardware runs few launches at once) for as long as a launch of fifty.
+    int32_t hold_us = 0;
+    Graveyard graveyard;
+    // counters (cramgpu_coalesce_stats)
+    int64_t n_batches = 0, n_subs = 0, largest = 0;
+    bool trace = false;  // CRAMGPU_COALESCE_TRACE=1: one line per batch on stderr (host clock, ms since the queue opened)
+    std::chrono::steady_clock::time_point t0;
+    double now() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+namespace {
+
+size_t co_round(size_t n) { return std::max<size_t>(n, 1 << 20); }
+
+int co_launch(cramgpu_coalescer* q, CoBatch* b) {
+    cramgpu_ctx* c = q->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (!b->stream) {
+        HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b->coded, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+    }
+    // arenas of the batch: the submissions' arenas back to back, their descriptors rebased
+    int64_t in_run = 0, out_run = 0, max_cap = 0;
+    b->blocks.clear();
+    for (CoSub* s : b->subs) {
+        s->in_base = in_run;
+        s->out_base = out_run;
+        s->first = (int32_t)b->blocks.size();
+        for (const cramgpu_block& blk : s->blocks) {
+            cramgpu_block r = blk;
+            r.in_off += in_run;
+            r.out_off += out_run;
+            b->blocks.push_back(r);
+        }
+        max_cap = std::max(max_cap, s->max_cap);
+        in_run += align_up(s->in_bytes, 16);
+        out_run += align_up(s->out_bytes, 16);
+    }
+    const int32_t n = (int32_t)b->blocks.size();
+    hipStream_t s = b->stream;
+    HIPCHK(b->d_in.reserve(co_round((size_t)in_run + 16)));
+    HIPCHK(b->d_out.reserve(co_round((size_t)out_run + 16)));
+    HIPCHK(b->d_len.reserve(co_round(n) / 4));
+    HIPCHK(b->d_pos.reserve(co_round(n) / 4));
+    HIPCHK(b->h_len.reserve(co_round(n) / 4));
+    HIPCHK(b->h_pos.reserve(co_round((size_t)n + 1) / 4));
+    // uploads first come first served on one stream (see cramgpu_ctx::upload_stream)
+    for (CoSub* u : b->subs)
+        if (u->in_bytes > 0)
+            HIPCHK(hipMemcpyAsync(b->d_in.p + u->in_base, u->in, (size_t)u->in_bytes, hipMemcpyHostToDevice, q->upload_stream));
+    HIPCHK(hipEventRecord(b->uploaded, q->upload_stream));
+    HIPCHK(hipStreamWaitEvent(s, b->uploaded, 0));
+    if (int rc = rans_run(c, b->res, !b->decode, b->d_in.p, b->d_out.p, b->blocks.data(), n, b->d_len.p,
+                          b->decode ? nullptr : b->d_pos.p, s))
+        return rc;
+    HIPCHK(hipMemcpyAsync(b->h_len.p, b->d_len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (!b->decode) {
+        HIPCHK(b->d_pack.reserve(co_round((size_t)out_run + 16)));
+        HIPCHK(b->d_off.reserve(co_round((size_t)n + 1) / 4));
+        HIPCHK(b->d_err.reserve(16));
+        HIPCHK(launch_gather(b->d_out.p, b->d_pos.p, b->d_len.p, n, 16, b->d_pack.p, out_run, b->d_off.p, b->d_err.p,
+                             (int32_t)std::min<int64_t>(max_cap, 0x7fffffff), s));
+        HIPCHK(hipMemcpyAsync(b->h_pos.p, b->d_off.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipEventRecord(b->coded, s));
+    return 0;
+}
+
+// phase 1 -> 2: lengths and positions are on the host, queue the copies of every submission's results into its own arena
+int co_fetch(cramgpu_coalescer* q, CoBatch* b) {
+    if (q->trace) b->t_coded = q->now();
+    for (CoSub* u : b->subs) {
+        const int32_t nb = (int32_t)u->blocks.size();
+        if (b->decode) {
+            if (u->hi > u->lo)
+                HIPCHK(hipMemcpyAsync(u->out + u->lo, b->d_out.p + u->out_base + u->lo, (size_t)(u->hi - u->lo),
+                                      hipMemcpyDeviceToHost, b->stream));
+            continue;
+        }
+        // the streams of one submission are neighbours in the packed arena
+        const int64_t p0 = b->h_pos.p[u->first], p1 = b->h_pos.p[u->first + nb];
+        if (p1 - p0 > u->out_bytes) {
+            u->rc = CRAMGPU_E_INSUFFICIENT;
+            u->err = "coalesced job: packed streams exceed the output arena";
+            continue;
+        }
+        if (p1 > p0) HIPCHK(hipMemcpyAsync(u->out, b->d_pack.p + p0, (size_t)(p1 - p0), hipMemcpyDeviceToHost, b->stream));
+    }
+    HIPCHK(hipEventRecord(b->done, b->stream));
+    return 0;
+}
+
+// phase 2 -> home: the copies have landed
+void co_deliver(CoBatch* b) {
+    for (CoSub* u : b->subs) {
+        const int32_t nb = (int32_t)u->blocks.size();
+        for (int32_t i = 0; i < nb; i++) u->out_len[i] = b->h_len.p[u->first + i];
+        if (b->decode || u->rc) continue;
+        const int64_t p0 = b->h_pos.p[u->first];
+        if (u->packed) {
+            for (int32_t i = 0; i <= nb; i++) u->out_pos[i] = b->h_pos.p[u->first + i] - p0;
+        } else {  // spread to the slots, last stream first (cramgpu_job_wait)
+            for (int32_t i = nb - 1; i >= 0; i--) {
+                const int32_t len = u->out_len[i];
+                const int64_t at = b->h_pos.p[u->first + i] - p0;
+                if (len > 0 && u->blocks[i].out_off != at) memmove(u->out + u->blocks[i].out_off, u->out + at, (size_t)len);
+            }
+        }
+    }
+}
+
+void co_finish(cramgpu_coalescer* q, CoBatch* b, int rc) {  // under q->mu
+    for (CoSub* u : b->subs) {
+        if (rc && !u->rc) {
+            u->rc = rc;
+            u->err = g_err;
+        }
+        u->state = 2;
+    }
+    b->subs.clear();
+    q->free_batches.push_back(b);
+}
+
+void co_dispatch_loop(cramgpu_coalescer* q) {
+    tl_graveyard = &q->graveyard;
+    std::unique_lock<std::mutex> lk(q->mu);
+    for (;;) {
+        q->cv_work.wait(lk, [&] { return q->stop || (!q->queue.empty() && !q->free_batches.empty()); });
+        if (q->stop) return;
+        if (q->hold_us > 0 && !q->inflight.empty() && (int32_t)q->queue.size() < q->max_subs) {
+            const auto until = q->queue.front()->arrived + std::chrono::microseconds(q->hold_us);
+            if (std::chrono::steady_clock::now() < until) {
+                q->cv_work.wait_until(lk, until, [&] { return q->stop || (int32_t)q->queue.size() >= q->max_subs; });
+                continue;  // look again: the queue has grown, or the hold has run out
+            }
+        }
+        CoBatch* b = q->free_batches.back();
+        q->free_batches.pop_back();
+        b->decode = q->queue.front()->decode;
+        b->subs.clear();
+        int64_t in_run = 0;
+        while (!q->queue.empty() && (int32_t)b->subs.size() < q->max_subs) {
+            CoSub* u = q->queue.front();
+            if (u->decode != b->decode) break;  // one direction per launch; the other one goes into the next batch
+            if (!b->subs.empty() && in_run + u->in_bytes > q->max_in_bytes) break;
+            in_run += align_up(u->in_bytes, 16);
+            u->state = 1;
+            b->subs.push_back(u);
+            q->queue.pop_front();
+        }
+        q->n_batches++;
+        q->n_subs += (int64_t)b->subs.size();
+        q->largest = std::max<int64_t>(q->largest, (int64_t)b->subs.size());
+        lk.unlock();
+        if (q->trace) b->t_pick = q->now();
+        const int rc = co_launch(q, b);
+        if (q->trace) b->t_issued = q->now();
+        lk.lock();
+        if (rc) {
+            co_finish(q, b, rc);
+            q->cv_done.notify_all();
+        } else {
+            b->phase = 1;
+            q->inflight.push_back(b);
+            q->cv_flight.notify_one();
+        }
+    }
+}
+
+// Brings batches home in the order they FINISH (a short batch launched behind a long one is not kept waiting): polls
+// the events of everything in flight, sleeping a few tens of microseconds between rounds.
+void co_complete_loop(cramgpu_coalescer* q) {
+    (void)hipSetDevice(q->ctx->device);
+    std::unique_lock<std::mutex> lk(q->mu);
+    std::vector<CoBatch*> fl;
+    for (;;) {
+        q->cv_flight.wait(lk, [&] { return !q->inflight.empty() || q->stop; });
+        if (q->inflight.empty()) return;  // stop: batches in flight are still brought home first
+        fl.assign(q->inflight.begin(), q->inflight.end());
+        lk.unlock();
+        bool progress = false;
+        for (CoBatch* b : fl) {
+            int rc = 0;
+            bool home = false;
+            hipError_t e = hipEventQuery(b->phase == 1 ? b->coded : b->done);
+            if (e == hipErrorNotReady) continue;
+            progress = true;
+            if (e != hipSuccess) {
+                rc = fail(CRAMGPU_E_HIP, "coalesced job", e);
+                home = true;
+            } else if (b->phase == 1) {
+                rc = co_fetch(q, b);
+                b->phase = 2;
+                home = rc != 0;
+            } else {
+                co_deliver(b);
+                home = true;
+            }
+            if (!home) continue;
+            if (q->trace)
+                fprintf(stderr, "[cramgpu coalesce] batch of %3zu (%s): picked %9.3f, issued +%.3f, coded +%.3f, home +%.3f ms\n", b->subs.size(),
+                        b->decode ? "decode" : "encode", b->t_pick, b->t_issued - b->t_pick, b->t_coded - b->t_pick, q->now() - b->t_pick);
+            lk.lock();
+            q->inflight.erase(std::find(q->inflight.begin(), q->inflight.end(), b));
+            co_finish(q, b, rc);
+            lk.unlock();
+            q->cv_done.notify_all();
+            q->cv_work.notify_one();
+        }
+        if (!progress) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        lk.lock();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+cramgpu_coalescer* cramgpu_coalescer_open(cramgpu_ctx* c, int32_t max_batches) {
+    if (!c) {
+        fail(CRAMGPU_E_ARG, "coalescer: null context");
+        return nullptr;
+    }
+    if (max_batches <= 0) max_batches = env_int("CRAMGPU_COALESCE_BATCHES", 6);
+    max_batches = std::min(max_batches, 16);
+    if (hipSetDevice(c->device) != hipSuccess) {
+        fail(CRAMGPU_E_HIP, "hipSetDevice failed");
+        return nullptr;
+    }
+    cramgpu_coalescer* q = new cramgpu_coalescer();
+    q->ctx = c;
+    q->batches.resize((size_t)max_batches);
+    for (auto& b : q->batches) q->free_batches.push_back(&b);
+    q->max_in_bytes = (int64_t)env_int("CRAMGPU_COALESCE_MAX_MB", 1024) << 20;
+    q->max_subs = env_int("CRAMGPU_COALESCE_MAX_SUBS", 1024);
+    q->hold_us = env_int("CRAMGPU_COALESCE_HOLD_US", 300);
+    q->trace = env_int("CRAMGPU_COALESCE_TRACE", 0) != 0;
+    q->t0 = std::chrono::steady_clock::now();
+    if (hipStreamCreateWithFlags(&q->upload_stream, hipStreamNonBlocking) != hipSuccess) {
+        fail(CRAMGPU_E_HIP, "coalescer: stream creation failed");
+        delete q;
+        return nullptr;
+    }
+    q->dispatcher = std::thread(co_dispatch_loop, q);
+    q->completer = std::thread(co_complete_loop, q);
+    return q;
+}
+
+void cramgpu_coalescer_close(cramgpu_coalescer* q) {
+    if (!q) return;
+    {
+        std::unique_lock<std::mutex> lk(q->mu);
+        q->stop = true;
+        // submissions nobody launched yet are refused, batches in flight come home
+        for (CoSub* u : q->queue) {
+            u->rc = CRAMGPU_E_ARG;
+            u->err = "coalescer closed";
+            u->state = 2;
+        }
+        q->queue.clear();
+    }
+    q->cv_work.notify_all();
+    q->cv_flight.notify_all();
+    q->cv_done.notify_all();
+    if (q->dispatcher.joinable()) q->dispatcher.join();
+    q->cv_flight.notify_all();
+    if (q->completer.joinable()) q->completer.join();
+    (void)hipSetDevice(q->ctx->device);
+    for (auto& b : q->batches) {
+        if (b.stream) (void)hipStreamSynchronize(b.stream);
+        b.res.release();
+        b.d_in.release(); b.d_out.release(); b.d_pack.release(); b.d_len.release(); b.d_err.release();
+        b.d_pos.release(); b.d_off.release(); b.h_len.release(); b.h_pos.release();
+        if (b.stream) (void)hipStreamDestroy(b.stream);
+        if (b.uploaded) (void)hipEventDestroy(b.uploaded);
+        if (b.coded) (void)hipEventDestroy(b.coded);
+        if (b.done) (void)hipEventDestroy(b.done);
+    }
+    if (q->upload_stream) (void)hipStreamDestroy(q->upload_stream);
+    for (void* p : q->graveyard.dev) (void)hipFree(p);
+    for (void* p : q->graveyard.pin) (void)hipHostFree(p);
+    for (auto& kv : q->tickets) delete kv.second;
+    delete q;
+}
+
+int64_t cramgpu_rans_enqueue(cramgpu_coalescer* q, int32_t decode, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                             int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len, int64_t* out_pos) {
+    if (!q || n <= 0 || in_bytes < 0 || out_bytes < 0 || !in_arena || !out_arena || !blocks || !out_len)
+        return fail(CRAMGPU_E_ARG, "enqueue: bad argument");
+    int64_t max_cap = 0, lo = out_bytes, hi = 0, prev_end = 0;
+    for (int32_t i = 0; i < n; i++) {
+        const cramgpu_block& b = blocks[i];
+        if (b.in_off < 0 || b.out_off < 0 || (b.in_off % CRAMGPU_ARENA_ALIGN) || (!decode && (b.out_off % CRAMGPU_ARENA_ALIGN)))
+            return fail(CRAMGPU_E_ARG, "block offsets must be non-negative multiples of CRAMGPU_ARENA_ALIGN");
+        if (b.in_len < 0 || b.out_cap < 0) return fail(CRAMGPU_E_ARG, "negative block size");
+        if (b.in_off + b.in_len > in_bytes || b.out_off + b.out_cap > out_bytes)
+            return fail(CRAMGPU_E_ARG, "enqueue: block outside its arena");
+        if (!decode && !out_pos && b.out_off < prev_end)
+            return fail(CRAMGPU_E_ARG, "enqueue: output slots must be ascending and must not overlap");
+        prev_end = b.out_off + b.out_cap;
+        max_cap = std::max<int64_t>(max_cap, b.out_cap);
+        lo = std::min<int64_t>(lo, b.out_off);
+        hi = std::max<int64_t>(hi, b.out_off + b.out_cap);
+    }
+    CoSub* u = new CoSub();
+    u->decode = decode != 0;
+    u->packed = !decode && out_pos != nullptr;
+    u->in = in_arena;
+    u->out = out_arena;
+    u->in_bytes = in_bytes;
+    u->out_bytes = out_bytes;
+    u->blocks.assign(blocks, blocks + n);
+    u->out_len = out_len;
+    u->out_pos = out_pos;
+    u->lo = lo;
+    u->hi = hi;
+    u->max_cap = max_cap;
+    int64_t id;
+    {
+        std::lock_guard<std::mutex> lk(q->mu);
+        if (q->stop) {
+            delete u;
+            return fail(CRAMGPU_E_ARG, "enqueue: coalescer closed");
+        }
+        id = u->id = q->next_id++;
+        u->arrived = std::chrono::steady_clock::now();
+        q->tickets[id] = u;
+        q->queue.push_back(u);
+    }
+    q->cv_work.notify_one();
+    return id;
+}
+
+int32_t cramgpu_ticket_poll(cramgpu_coalescer* q, int64_t ticket) {
+    if (!q) return fail(CRAMGPU_E_ARG, "poll: null coalescer");
+    std::lock_guard<std::mutex> lk(q->mu);
+    auto it = q->tickets.find(ticket);
+    if (it == q->tickets.end()) return fail(CRAMGPU_E_ARG, "poll: no such ticket");
+    return it->second->state == 2 ? 1 : 0;
+}
+
+int32_t cramgpu_ticket_wait(cramgpu_coalescer* q, int64_t ticket) {
+    if (!q) return fail(CRAMGPU_E_ARG, "wait: null coalescer");
+    std::unique_lock<std::mutex> lk(q->mu);
+    auto it = q->tickets.find(ticket);
+    if (it == q->tickets.end()) return fail(CRAMGPU_E_ARG, "wait: no such ticket");
+    CoSub* u = it->second;
+    q->cv_done.wait(lk, [&] { return u->state == 2; });
+    q->tickets.erase(it);
+    lk.unlock();
+    const int32_t rc = u->rc;
+    if (rc) g_err = u->err;
+    delete u;
+    return rc;
+}
+
+int32_t cramgpu_rans_coalesced(cramgpu_coalescer* q, int32_t decode, const uint8_t* in_arena, int64_t in_bytes, uint8_t* out_arena,
+                               int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len, int64_t* out_pos) {
+    const int64_t t = cramgpu_rans_enqueue(q, decode, in_arena, in_bytes, out_arena, out_bytes, blocks, n, out_len, out_pos);
+    if (t < 0) return (int32_t)t;
+    return cramgpu_ticket_wait(q, t);
+}
+
+int32_t cramgpu_coalesce_stats(cramgpu_coalescer* q, int64_t* n_batches, int64_t* n_submissions, int64_t* largest_batch) {
+    if (!q) return fail(CRAMGPU_E_ARG, "stats: null coalescer");
+    std::lock_guard<std::mutex> lk(q->mu);
+    if (n_batches) *n_batches = q->n_batches;
+    if (n_submissions) *n_submissions = q->n_subs;
+    if (largest_batch) *largest_batch = q->largest;
+    return 0;
 }
 
 // ---- level 0 ----

@@ -333,3 +333,73 @@ class _Job:
             return res
         finally:
             self._free()
+
+
+class Coalescer:
+    """The coalescing queue of one Engine (cramgpu_coalescer_*): the form for hosts that keep the reference's thread
+    model, one container per worker thread (paralell/TransformerJob.java:29-41).  `rans(datas, orders)` /
+    `unrans(streams)` are blocking and may be called from any number of threads at once; the library turns the calls
+    that are waiting at the same moment into ONE launch."""
+
+    def __init__(self, eng, max_batches=0):
+        self.eng = eng
+        self._q = _lib.lib().cramgpu_coalescer_open(eng.handle, max_batches)
+        if not self._q:
+            raise CramGpuError(_lib.E_ARG, _lib.last_error())
+
+    @property
+    def handle(self):
+        return self._q
+
+    def close(self):
+        if self._q:
+            _lib.lib().cramgpu_coalescer_close(self._q)
+            self._q = None
+
+    def stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().cramgpu_coalesce_stats(self._q, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(batches=a.value, submissions=b.value, largest_batch=c.value)
+
+    def _run(self, items, orders, decode):
+        L = _lib.lib()
+        n = len(items)
+        if n == 0:
+            return []
+        if decode:
+            raws = []
+            for s in items:
+                b = np.frombuffer(bytes(s), np.uint8)
+                raws.append(0 if b.size == 0 else _lib.check(L.cramgpu_rans_raw_size(b.ctypes.data, b.size)))
+            blocks, in_bytes, out_bytes = Engine.plan_decode([len(s) for s in items], raws)
+        else:
+            blocks, in_bytes, out_bytes = Engine.plan_encode([len(d) for d in items], orders)
+        h_in, h_out, h_len = L.cramgpu_host_alloc(in_bytes), L.cramgpu_host_alloc(max(out_bytes, 16)), L.cramgpu_host_alloc(4 * n)
+        try:
+            if not (h_in and h_out and h_len):
+                raise CramGpuError(_lib.E_HIP, "cramgpu_host_alloc failed")
+            arena = np.ctypeslib.as_array(C.cast(h_in, C.POINTER(C.c_uint8)), shape=(in_bytes,))
+            arena[:] = 0
+            for i, d in enumerate(items):
+                arena[blocks[i].in_off:blocks[i].in_off + len(d)] = np.frombuffer(bytes(d), np.uint8)
+            _lib.check(L.cramgpu_rans_coalesced(self._q, 1 if decode else 0, h_in, in_bytes, h_out, out_bytes,
+                                                C.addressof(blocks), n, h_len, None))
+            out = np.ctypeslib.as_array(C.cast(h_out, C.POINTER(C.c_uint8)), shape=(max(out_bytes, 16),))
+            lens = np.ctypeslib.as_array(C.cast(h_len, C.POINTER(C.c_int32)), shape=(n,))
+            res = []
+            for i in range(n):
+                if lens[i] < 0:
+                    raise CramGpuError(int(lens[i]), "block %d" % i)
+                res.append(out[blocks[i].out_off:blocks[i].out_off + lens[i]].tobytes())
+            return res
+        finally:
+            for p in (h_in, h_out, h_len):
+                if p:
+                    L.cramgpu_host_free(p)
+
+    def rans(self, datas, orders):
+        """ExternalCompression.rans over the blocks of one container, coalesced with the other threads' calls."""
+        return self._run(datas, orders, False)
+
+    def unrans(self, streams):
+        return self._run(streams, None, True)

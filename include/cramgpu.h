@@ -172,6 +172,33 @@ cramgpu_job* cramgpu_rans_submit_packed(cramgpu_ctx* ctx, const uint8_t* in_aren
 int32_t cramgpu_job_poll(cramgpu_job* job);
 int32_t cramgpu_job_wait(cramgpu_job* job);
 
+/* Coalescing queue: the form for a host that keeps the reference's thread model, ONE container per worker thread
+ * (paralell/TransformerJob.java:29-41 runs one BamToCram_OBA_Function / CramToBam_OBA_Function per stripe,
+ * BamToCram.java:146-155 feeds them, CRAMContainerAsynchWriter.java:139-149 runs a Batch per container).  A launch
+ * per container lasts one chain latency (the container's longest block) whatever its size, so the library commits in
+ * groups: every worker calls cramgpu_rans_coalesced (blocking; or cramgpu_rans_enqueue + cramgpu_ticket_wait) with its
+ * own container; a dispatcher thread of the queue turns ALL submissions waiting at that moment into one launch as soon
+ * as one of `max_batches` batch slots (own stream and launch resources each; 0 = 6) is free, and a completer thread
+ * copies every submission's streams into its own out_arena and wakes its caller.  Arguments and results are those of
+ * cramgpu_rans_submit (out_pos == NULL: streams at the starts of their slots, decode: raw blocks at out_off) or
+ * cramgpu_rans_submit_packed (out_pos != NULL).  Any number of threads may call at once; tickets are positive, a
+ * negative return is a CRAMGPU_E_* code.  A ticket is released by its wait.  Arenas should be pinned
+ * (cramgpu_host_alloc) and must stay untouched until the wait returns.  cramgpu_coalescer_close waits for the batches
+ * in flight and refuses what was never launched (CRAMGPU_E_ARG at its wait); close it before its context. */
+typedef struct cramgpu_coalescer cramgpu_coalescer;
+cramgpu_coalescer* cramgpu_coalescer_open(cramgpu_ctx* ctx, int32_t max_batches);
+void cramgpu_coalescer_close(cramgpu_coalescer* q);
+int64_t cramgpu_rans_enqueue(cramgpu_coalescer* q, int32_t decode, const uint8_t* in_arena, int64_t in_bytes,
+                             uint8_t* out_arena, int64_t out_bytes, const cramgpu_block* blocks, int32_t n_blocks,
+                             int32_t* out_len, int64_t* out_pos);
+int32_t cramgpu_ticket_poll(cramgpu_coalescer* q, int64_t ticket);
+int32_t cramgpu_ticket_wait(cramgpu_coalescer* q, int64_t ticket);
+int32_t cramgpu_rans_coalesced(cramgpu_coalescer* q, int32_t decode, const uint8_t* in_arena, int64_t in_bytes,
+                               uint8_t* out_arena, int64_t out_bytes, const cramgpu_block* blocks, int32_t n_blocks,
+                               int32_t* out_len, int64_t* out_pos);
+/* launches made, submissions served and the most submissions one launch held, since the queue was opened */
+int32_t cramgpu_coalesce_stats(cramgpu_coalescer* q, int64_t* n_batches, int64_t* n_submissions, int64_t* largest_batch);
+
 /* =====================================================================================================
  * Level 2 — record kernels over one container in flat (structure-of-arrays) form.
  * ===================================================================================================== */

@@ -1,0 +1,127 @@
+"""The coalescing queue (cramgpu_coalescer_*, cramgpu_rans_coalesced / _enqueue / cramgpu_ticket_*): one container per
+caller, many callers at once — the thread model of paralell/TransformerJob.java:29-41 — against the CPU oracle."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def xc():
+    from cramtools_amd import external_compression as x
+    return x
+
+
+@pytest.fixture(scope="module")
+def engine(xc):
+    e = xc.Engine(0)
+    yield e
+    e.close()
+
+
+N_THREADS, N_WINDOW, LONG = 48, 32, 40000  # the host-build glue test (tests/test_glue_hostsim.py) shrinks these
+
+
+def container(rng, k):
+    """Blocks shaped like one container's rANS series: a long order-1 block of scores and a few short ones."""
+    lens = (LONG + 97 * k, 3000 + k, 700, 5, 0, 1500)
+    datas = [rng.integers(0, 3 + (7 * k + 11 * i) % 200, n, dtype=np.uint8).tobytes() for i, n in enumerate(lens)]
+    return datas, [1, 0, 1, 1, 0, 0]
+
+
+def test_many_threads_one_container_each(engine, xc, orc):
+    rng = np.random.default_rng(5)
+    conts = [container(rng, k) for k in range(N_THREADS)]
+    q = xc.Coalescer(engine)
+    got, raws, errs = [None] * len(conts), [None] * len(conts), []
+
+    def worker(k):
+        try:
+            got[k] = q.rans(*conts[k])
+            raws[k] = q.unrans(got[k])
+        except Exception as e:  # noqa: BLE001 — reported by the main thread
+            errs.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(conts))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    st = q.stats()
+    q.close()
+    assert not errs, errs
+    for k, (datas, orders) in enumerate(conts):
+        assert got[k] == [orc.rans(d, o) for d, o in zip(datas, orders)], k
+        assert raws[k] == datas, k
+    assert st["submissions"] == 2 * len(conts)
+    assert st["batches"] < st["submissions"]  # calls that waited together shared launches
+    assert st["largest_batch"] > 1
+
+
+def test_enqueue_window_packed(engine, xc, orc):
+    """cramgpu_rans_enqueue with out_pos (the packed form) from ONE thread, 32 tickets outstanding; poll / wait;
+    a ticket is gone after its wait."""
+    from cramtools_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(9)
+    conts = [container(rng, k) for k in range(N_WINDOW)]
+    q = xc.Coalescer(engine, 2)
+    held = []
+    for datas, orders in conts:
+        n = len(datas)
+        blocks, in_bytes, out_bytes = xc.Engine.plan_encode([len(d) for d in datas], orders)
+        h_in = np.zeros(in_bytes, np.uint8)
+        for i, d in enumerate(datas):
+            h_in[blocks[i].in_off:blocks[i].in_off + len(d)] = np.frombuffer(d, np.uint8)
+        h_out, h_len, h_pos = np.zeros(out_bytes, np.uint8), np.zeros(n, np.int32), np.zeros(n + 1, np.int64)
+        t = L.cramgpu_rans_enqueue(q.handle, 0, h_in.ctypes.data, in_bytes, h_out.ctypes.data, out_bytes, C.addressof(blocks), n,
+                                   h_len.ctypes.data, h_pos.ctypes.data)
+        assert t > 0, _lib.last_error()
+        held.append((t, blocks, h_in, h_out, h_len, h_pos))
+    while L.cramgpu_ticket_poll(q.handle, held[0][0]) == 0:
+        pass
+    for (t, blocks, h_in, h_out, h_len, h_pos), (datas, orders) in zip(held, conts):
+        assert L.cramgpu_ticket_wait(q.handle, t) == 0, _lib.last_error()
+        for i, (d, o) in enumerate(zip(datas, orders)):
+            assert h_pos[i] % 16 == 0
+            assert h_out[h_pos[i]:h_pos[i] + h_len[i]].tobytes() == orc.rans(d, o)
+        assert L.cramgpu_ticket_wait(q.handle, t) == _lib.E_ARG
+    q.close()
+
+
+def test_bad_submissions_and_capacity(engine, xc, orc):
+    """A refused submission (misaligned / negative / outside its arena) never reaches a batch; an out arena too small
+    for the packed streams fails that ticket only; a stream that does not decode gives its own block's code."""
+    from cramtools_amd import _lib
+    L = _lib.lib()
+    q = xc.Coalescer(engine)
+    data = np.arange(5000, dtype=np.uint8).tobytes()
+    blocks, in_bytes, out_bytes = xc.Engine.plan_encode([len(data)], [0])
+    h_in = np.zeros(in_bytes, np.uint8)
+    h_in[:len(data)] = np.frombuffer(data, np.uint8)
+    h_out, h_len, h_pos = np.zeros(out_bytes, np.uint8), np.zeros(1, np.int32), np.zeros(2, np.int64)
+    args = lambda b, ib=in_bytes, ob=out_bytes: (q.handle, 0, h_in.ctypes.data, ib, h_out.ctypes.data, ob, C.addressof(b), 1,
+                                                 h_len.ctypes.data, h_pos.ctypes.data)
+    for field, val in (("in_off", 8), ("in_len", -1), ("out_cap", -5), ("in_len", in_bytes + 1)):
+        b = (xc.Block * 1)(xc.Block(blocks[0].in_off, blocks[0].out_off, blocks[0].in_len, blocks[0].out_cap, 0, 0))
+        setattr(b[0], field, val)
+        assert L.cramgpu_rans_enqueue(*args(b)) == _lib.E_ARG
+    # the device codes into a bound-sized slot; the caller's arena only has to hold the packed streams
+    small = (xc.Block * 1)(xc.Block(0, 0, len(data), 16, 0, 0))
+    s_out, s_len, s_pos = np.zeros(16, np.uint8), np.zeros(1, np.int32), np.zeros(2, np.int64)
+    t_small = L.cramgpu_rans_enqueue(q.handle, 0, h_in.ctypes.data, in_bytes, s_out.ctypes.data, 16, C.addressof(small), 1,
+                                     s_len.ctypes.data, s_pos.ctypes.data)
+    good = L.cramgpu_rans_enqueue(*args(blocks))
+    assert t_small > 0 and good > 0
+    assert L.cramgpu_ticket_wait(q.handle, t_small) == 0 and s_len[0] < 0  # the block itself reports the small slot
+    assert L.cramgpu_ticket_wait(q.handle, good) == 0, _lib.last_error()
+    assert h_out[:h_len[0]].tobytes() == orc.rans(data, 0)
+    stream = bytearray(orc.rans(data, 1))
+    stream[1:5] = (len(stream) + 40).to_bytes(4, "little")  # compressed size beyond the stream
+    with pytest.raises(_lib.CramGpuError):
+        q.unrans([bytes(stream)])
+    assert q.unrans([orc.rans(data, 1)]) == [data]
+    q.close()

@@ -81,6 +81,22 @@ def test_rans_gpu_test_bodies(hostsim, kat1, orc, monkeypatch):
         eng.close()
 
 
+def test_coalescer_test_bodies(hostsim, orc, monkeypatch):
+    """The coalescing queue (dispatcher / completer threads, tickets) over the host build: tests/test_coalesce_gpu.py."""
+    import test_coalesce_gpu as t
+    from cramtools_amd import external_compression as xc
+    monkeypatch.setattr(t, "N_THREADS", 6)
+    monkeypatch.setattr(t, "N_WINDOW", 5)
+    monkeypatch.setattr(t, "LONG", 2000)
+    eng = xc.Engine(0)
+    try:
+        t.test_many_threads_one_container_each(eng, xc, orc)
+        t.test_enqueue_window_packed(eng, xc, orc)
+        t.test_bad_submissions_and_capacity(eng, xc, orc)
+    finally:
+        eng.close()
+
+
 def test_records_gpu_test_bodies(hostsim, katrec, orc, monkeypatch):
     import test_records_gpu as t
     from cramtools_amd import external_compression as xc
