@@ -255,6 +255,147 @@ class Step:
             self.enc_ms.append(self.ev[0].elapsed_time(self.ev[1]))
 
 
+    # ---- the whole container, as CramSerilization.java:108-200 does it, in ONE timed region (missing 2) ----
+    def prepare_full(self):
+        """Set-up of run_full (untimed): read names (ten decimal digits of the read's index: every name occurs once, so
+        #setMateInfo must find every record detached, which is what the corpus' CF column says), alignment ends and slice
+        spans from the CIGARs, output buffers."""
+        w, dev, reads = self.w, self.dev, self.w["reads"]
+        n, n_cont = reads.n, w["n_cont"]
+        idx = torch.arange(n, device=dev, dtype=torch.int64)
+        self.names = ((idx[:, None] // (10 ** torch.arange(9, -1, -1, device=dev, dtype=torch.int64))[None, :]) % 10 + 48).to(torch.uint8).reshape(-1).contiguous()
+        self.name_off, self.name_len = (idx * 10).contiguous(), torch.full((n,), 10, dtype=torch.int32, device=dev)
+        op, ln = (reads.cigar & 15).to(torch.int64), (reads.cigar >> 4).to(torch.int64)
+        owner = torch.repeat_interleave(torch.arange(n, device=dev), reads.n_cigar.to(torch.int64))
+        span = torch.zeros(n, dtype=torch.int64, device=dev)
+        on_ref = (op == 0) | (op == 2) | (op == 3) | (op == 7) | (op == 8)
+        span.index_add_(0, owner, torch.where(on_ref, ln, torch.zeros_like(ln))[:owner.numel()])
+        self.aln_end = (reads.aln_start.to(torch.int64) + span - 1).to(torch.int32)
+        self.cont_first = torch.as_tensor(np.minimum(np.arange(n_cont + 1, dtype=np.int64) * READS_PER_CONTAINER, n).astype(np.int32)).to(dev)
+        cont = reads.read_cont.to(torch.int64)
+        hi = torch.zeros(n_cont, dtype=torch.int64, device=dev).scatter_reduce_(0, cont, self.aln_end.to(torch.int64), "amax")
+        lo = reads.aln_start[self.cont_first[:-1].to(torch.int64)].to(torch.int64)
+        self.sl_start, self.sl_span = lo.to(torch.int32), (hi - lo + 1).to(torch.int32)
+        self.sl_win = reads.win  # (ref_off, ref_len, ref_start0) per container: the whole contig on encode
+        self.md5 = torch.zeros(n_cont * 16, dtype=torch.uint8, device=dev)
+        self.crc = torch.zeros(n_cont * 2, dtype=torch.int32, device=dev)
+        self.rest = np.array([k for k in range(_lib.N_SERIES) if k not in set(self.ids.tolist())])
+        self.gz_piece = 8192
+        self.gz_desc = None
+        self.side = torch.cuda.Stream(device=dev)
+        self.ev_full = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self.full_ms = []
+        from cramtools_amd import bam as bam_mod
+        self.ser = bam_mod.CramSerilization(self.eng, dev)
+
+    def _gzip_plan(self, off, ln):
+        """Descriptors of the GZIP series (every series the fixed map does not give to rANS), longer ones cut into pieces
+        of gz_piece bytes, one member each, longest first; numpy only (inside the timed region)."""
+        o, l = off[:, self.rest].reshape(-1), ln[:, self.rest].reshape(-1)
+        keep = l > 0
+        o, l = o[keep], l[keep]
+        k = (l + self.gz_piece - 1) // self.gz_piece
+        src = np.repeat(o, k)
+        within = np.arange(int(k.sum()), dtype=np.int64) - np.repeat(np.cumsum(k) - k, k)
+        start = within * self.gz_piece
+        pl = np.minimum(self.gz_piece, np.repeat(l, k) - start)
+        d = np.zeros(pl.size, BLOCK_DTYPE)
+        d["in_off"], d["in_len"] = src + start, pl
+        cap = (pl + 5 * ((pl >> 15) + 1) + 64 + 15) // 16 * 16  # >= cramgpu_gzip_bound: input + 5 per stored block + header / trailer
+        d["out_cap"] = cap
+        d["out_off"] = np.cumsum(cap) - cap
+        return d[np.argsort(-pl, kind="stable")], int(cap.sum())
+
+    def run_full(self, timed):
+        """K3 -> F3 -> #setMateInfo -> W -> (K1 beside Z: the GZIP series written as gzip members on a second stream) ->
+        slice reference MD5 -> ContentDigests -> gather, one region."""
+        w, L = self.w, _lib.lib()
+        reads, cols = w["reads"], w["cols"]
+        main = torch.cuda.current_stream()
+        if timed:
+            self.ev_full[0].record()
+        self.hist.zero_()
+        rs_, fs_ = reads.struct(), self.feats.struct()
+        self.feats.count = int(_lib.check(L.cramgpu_extract_features_dev(self.eng.handle, C.byref(rs_), w["ref"].data_ptr(), C.byref(fs_),
+                                                                         self.hist.data_ptr(), main.cuda_stream)))
+        self.fac.matrices_and_codes(reads, self.feats, self.hist, self.mats)
+        self.ser.set_mate_info(cols, self.cont_first, reads.aln_start, self.aln_end, self.names, self.name_off, self.name_len)
+        self.writer.write(reads, cols, self.feats)
+        off, ln = self.writer.lengths()
+        blk = self.blk
+        blk["in_off"], blk["in_len"] = off[:, self.ids].reshape(-1), ln[:, self.ids].reshape(-1)
+        cap = (1.05 * blk["in_len"].astype(np.float64) + 257.0 * 257.0 * 3.0 + 4.0).astype(np.int32)
+        blk["out_cap"] = cap
+        slot = (cap.astype(np.int64) + 15) // 16 * 16
+        blk["out_off"] = np.cumsum(slot) - slot
+        p_arena = self.writer.arena.data_ptr()
+        base = min(p_arena, reads.quals.data_ptr()) & ~15
+        blk["in_off"] += p_arena - base
+        gd, gz_bytes = self._gzip_plan(off, ln)
+        if self.gz_desc is None:  # first (warm-up) call: buffers with headroom for later calls
+            self.gz_desc = torch.zeros(int(gd.size * 1.25) + 1024, BLOCK_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
+            self.gz_out = torch.zeros(int(gz_bytes * 1.25) + (1 << 20), dtype=torch.uint8, device=self.dev)
+            self.gz_len = torch.zeros(self.gz_desc.shape[0], dtype=torch.int32, device=self.dev)
+            self.gz_pin = torch.zeros(self.gz_desc.shape[0], BLOCK_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+        assert gd.size <= self.gz_desc.shape[0] and gz_bytes + 16 <= self.gz_out.numel()
+        self.gz_pin[:gd.size] = torch.from_numpy(gd.view(np.uint8).reshape(gd.size, -1))
+        self.gz_desc[:gd.size].copy_(self.gz_pin[:gd.size], non_blocking=True)
+        self.n_gz, self.gz_plan = int(gd.size), gd
+        self.side.wait_stream(main)
+        self.eng.encode_dev(base, self.d_out, blk, w["n_blocks"], self.d_len, self.d_pos)
+        with torch.cuda.stream(self.side):  # launched after K1: the chain waves take their SIMDs first, Z fills the rest
+            self.eng.gzip_dev(self.writer.arena, self.gz_out, self.gz_desc, self.n_gz, self.gz_len)
+        _lib.check(L.cramgpu_slice_md5_dev(self.eng.handle, w["n_cont"], w["ref"].data_ptr(), self.sl_win.data_ptr(),
+                                           self.sl_start.data_ptr(), self.sl_span.data_ptr(), self.md5.data_ptr(), main.cuda_stream))
+        _lib.check(L.cramgpu_content_digests_dev(self.eng.handle, reads.n, w["n_cont"], self.cont_first.data_ptr(),
+                                                 reads.base_off.data_ptr(), reads.read_len.data_ptr(), reads.bases.data_ptr(),
+                                                 reads.quals.data_ptr(), self.crc.data_ptr(), main.cuda_stream))
+        self.eng.gather_dev(self.d_out, self.d_pos, self.d_len, w["n_blocks"], w["max_cap"], self.d_pack, self.d_pack_off)
+        main.wait_stream(self.side)
+        if timed:
+            self.ev_full[1].record()
+            torch.cuda.synchronize()
+            self.full_ms.append(self.ev_full[0].elapsed_time(self.ev_full[1]))
+
+    def verify_full(self):
+        """What run_full left: every record detached (names are unique), slice MD5s and content digests of sampled
+        containers against hashlib / zlib, every gzip member inflated by the gunzip kernel back to its series piece."""
+        import hashlib
+        import zlib
+        w, reads, cols = self.w, self.w["reads"], self.w["cols"]
+        assert bool(((cols.comp_flags & 2) != 0).all().item()) and bool((cols.next_frag == -1).all().item()), "setMateInfo: a record is not detached"
+        ref_h = None
+        for c in (0, w["n_cont"] // 2, w["n_cont"] - 1):
+            lo, span = int(self.sl_start[c].item()), int(self.sl_span[c].item())
+            seg = w["ref"][lo - 1:lo - 1 + span].cpu().numpy().tobytes()
+            assert self.md5[16 * c:16 * c + 16].cpu().numpy().tobytes() == hashlib.md5(seg).digest(), "slice MD5 %d" % c
+            r0, r1 = int(self.cont_first[c].item()), int(self.cont_first[c + 1].item())
+            b0, b1 = int(reads.base_off[r0].item()), int(reads.base_off[r1 - 1].item()) + int(reads.read_len[r1 - 1].item())
+            bases, quals = reads.bases[b0:b1].cpu().numpy(), reads.quals[b0:b1].cpu().numpy()
+            offs = (reads.base_off[r0:r1] - b0).cpu().numpy()
+            lens = reads.read_len[r0:r1].cpu().numpy()
+            bd = sum(zlib.crc32(bases[o:o + l].tobytes()) for o, l in zip(offs, lens)) & 0xFFFFFFFF
+            sd = sum(zlib.crc32(quals[o:o + l].tobytes()) for o, l in zip(offs, lens)) & 0xFFFFFFFF
+            got = self.crc[2 * c:2 * c + 2].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            assert (int(got[0]), int(got[1])) == (bd, sd), "content digests %d" % c
+        n, gd = self.n_gz, self.gz_plan
+        zl = self.gz_len[:n].cpu().numpy()
+        assert (zl > 0).all(), "a GZIP series failed to compress"
+        back = np.zeros(n, BLOCK_DTYPE)
+        back["in_off"], back["in_len"], back["out_cap"] = gd["out_off"], zl, gd["in_len"]
+        pad = (gd["in_len"].astype(np.int64) + 31) // 16 * 16
+        back["out_off"] = np.cumsum(pad) - pad
+        d_back = torch.zeros(int(pad.sum()) + 16, dtype=torch.uint8, device=self.dev)
+        d_blen = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        self.eng.gunzip_dev(self.gz_out, d_back, torch.as_tensor(back.view(np.uint8).copy()).to(self.dev), n, d_blen)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_blen.cpu().numpy(), gd["in_len"]), "a gzip member does not inflate to its length"
+        for i in list(range(0, n, max(1, n // 64))) + [n - 1]:  # the bytes of a sample of members
+            a0, b0_, l = int(gd["in_off"][i]), int(back["out_off"][i]), int(gd["in_len"][i])
+            assert torch.equal(d_back[b0_:b0_ + l], self.writer.arena[a0:a0 + l]), "gzip member %d" % i
+        return dict(gzip_members=n, gzip_raw_bytes=int(gd["in_len"].sum()), gzip_bytes=int(zl.sum()))
+
+
 class DecodeStep:
     """configs[2]: the decode hot path over the streams one encode step produced (nothing allocated while timed):
       K2  rANS decode of every external block (from the gathered dense arena back into a raw arena),
@@ -390,6 +531,58 @@ class DecodeStep:
             self.ev[2].record()
             torch.cuda.synchronize()
             self.bam_ms.append(self.ev[3].elapsed_time(self.ev[2]))
+
+    # ---- the whole way out of a container, CramToBam_OBA_Function.java:53-83, in ONE timed region ----
+    def run_full(self, timed):
+        """K2 beside G -> R -> N1 / N2 -> A (CIGARs, mates, BAM records) -> the stripe as BGZF members (Z)."""
+        reads = self.w["reads"]
+        if not hasattr(self, "bgzf_img"):  # first (warm-up) call
+            piece, slot = 65280, 65536
+            nmax = (self.bam_cap + piece - 1) // piece
+            self.bgzf_desc_h = np.zeros(nmax, BLOCK_DTYPE)
+            self.bgzf_desc_h["in_off"] = np.arange(nmax, dtype=np.int64) * piece
+            self.bgzf_desc_h["out_off"] = np.arange(nmax, dtype=np.int64) * slot
+            self.bgzf_desc_h["out_cap"] = slot
+            self.bgzf_desc = torch.zeros(nmax, BLOCK_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
+            self.bgzf_img = torch.zeros(nmax * slot + 16, dtype=torch.uint8, device=self.dev)
+            self.bgzf_len = torch.zeros(nmax, dtype=torch.int32, device=self.dev)
+            self.ev_full = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            self.full_ms = []
+        if timed:
+            self.ev_full[0].record()
+        self.run(False)
+        self.assemble(False)
+        size = int(self.rec_off[reads.n].item())  # the host needs the stripe's size anyway (it writes the file)
+        piece = 65280
+        n = (size + piece - 1) // piece
+        d = self.bgzf_desc_h
+        d["in_len"][:n] = np.minimum(piece, size - d["in_off"][:n])
+        self.bgzf_desc[:n].copy_(torch.from_numpy(d[:n].view(np.uint8).reshape(n, -1)))
+        self.eng.gzip_dev(self.bam, self.bgzf_img, self.bgzf_desc, n, self.bgzf_len, bgzf=True)
+        self.bgzf_n, self.bam_bytes = n, size
+        if timed:
+            self.ev_full[1].record()
+            torch.cuda.synchronize()
+            self.full_ms.append(self.ev_full[0].elapsed_time(self.ev_full[1]))
+
+    def verify_full(self):
+        """Every BGZF member of run_full inflates (gunzip kernel) back to its piece of the stripe; four of them by zlib."""
+        import zlib
+        n, size, d = self.bgzf_n, self.bam_bytes, self.bgzf_desc_h
+        lens = self.bgzf_len[:n].cpu().numpy()
+        assert (lens > 0).all(), "a BGZF member failed"
+        b = np.zeros(n, BLOCK_DTYPE)
+        b["in_off"], b["out_off"], b["in_len"], b["out_cap"] = d["out_off"][:n], d["in_off"][:n], lens, d["in_len"][:n]
+        d_back = torch.zeros(size + 16, dtype=torch.uint8, device=self.dev)
+        d_blen = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        self.eng.gunzip_dev(self.bgzf_img, d_back, torch.as_tensor(b.view(np.uint8).copy()).to(self.dev), n, d_blen)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_blen.cpu().numpy(), d["in_len"][:n]) and torch.equal(d_back[:size], self.bam[:size]), "BGZF image -> stripe"
+        for k in (0, 1, n // 2, n - 1):
+            m = self.bgzf_img[int(d["out_off"][k]):int(d["out_off"][k]) + int(lens[k])].cpu().numpy().tobytes()
+            raw = self.bam[int(d["in_off"][k]):int(d["in_off"][k]) + int(d["in_len"][k])].cpu().numpy().tobytes()
+            assert m[12:14] == b"BC" and zlib.decompress(m, 31) == raw, "BGZF member %d" % k
+        return dict(bgzf_members=int(n), bam_bytes=int(size), bgzf_bytes=int(lens.sum()))
 
     def prepare(self):
         """Reader tables: where every series of every container lies (rANS series in the decoded arena, the others raw in
@@ -1172,6 +1365,7 @@ def main(argv=None, backend_factory=GpuBackend):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--no-full", action="store_true", help="skip the encode_full / decode_full regions")
     ap.add_argument("--no-bgzf", action="store_true", help="skip the BGZF image of the BAM stripe (2.7 GB through the gzip kernel)")
     ap.add_argument("--config", type=int, default=1, choices=(1, 4),
                     help="1: the headline (BASELINE.json configs[1] + the configs[2] decode leg); 4: configs[4], long reads + lossy model")
@@ -1270,6 +1464,26 @@ def main(argv=None, backend_factory=GpuBackend):
                     bam_decode_ms=getattr(dec, "bam_decode_ms", None))  # the stripe back into columns (BAMRecordCodec#decode)
                 if not a.no_bgzf and hasattr(dec, "bam_bytes"):
                     extra["decode"]["assembly"]["bgzf"] = bgzf_image(dec)
+        if not a.no_full and world == 1 and dec is not None and getattr(dec, "reader", None) is not None and hasattr(step, "run_full"):
+            step.prepare_full()
+            step.run_full(False)
+            for _ in range(a.steps):
+                step.run_full(True)
+            ef = float(np.mean(step.full_ms))
+            extra["encode_full"] = dict(
+                workload="one region per step, CramSerilization.java:108-200 per container: K3 -> F3 -> setMateInfo (unique read "
+                         "names: every record detached) -> W -> K1 beside Z (the %d non-rANS series as gzip members, pieces of 8 KiB) "
+                         "-> slice reference MD5 -> ContentDigests BD / SD -> gather" % len(step.rest),
+                ms=ef, value=w["raw_bytes"] / ef / 1e3, unit="MB/s", reads_per_s=a.reads / ef * 1e3, **step.verify_full())
+            dec.run_full(False)
+            for _ in range(a.steps):
+                dec.run_full(True)
+            df = float(np.mean(dec.full_ms))
+            extra["decode_full"] = dict(
+                workload="one region per step, CramToBam_OBA_Function.java:53-83 per container: K2 beside G -> R -> "
+                         "restoreReadBases / restoreQualityScores -> CIGARs, mate restoration, BAM records -> the stripe as BGZF "
+                         "members (Z)", ms=df, value=w["raw_bytes"] / df / 1e3, unit="MB/s", reads_per_s=a.reads / df * 1e3,
+                **dec.verify_full())
         if not a.no_pcie and world == 1:
             extra["pcie_inclusive"] = be.pcie(w)
             extra["pcie_inclusive"]["hw_queues"] = HW_QUEUES

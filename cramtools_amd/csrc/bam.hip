@@ -712,18 +712,28 @@ __global__ __launch_bounds__(256) void mate_decide_kernel(int32_t n, MateInfo M,
 // Slice content digests — htsjdk!cram/digest/ContentDigests as htsjdk!build/ContainerFactory#buildSlice drives it
 // (ContentDigests.create(ALL), add(record) per record, getAsTags() -> Slice.sliceTags).  BD / SD: java.util.zip.CRC32 of
 // every record's readBases / qualityScores (Crc32Hasher), the per-record values added as 32-bit integers
-// (IntegerSumCombine).  A thread per (record, series): CRC-32 (polynomial 0xEDB88320, the zlib one) byte by byte through
-// a table in LDS, then one atomic add per record into the slice's sum.
+// (IntegerSumCombine).  A thread per (record, series): CRC-32 (polynomial 0xEDB88320, the zlib one), sixteen bytes per
+// load and four bytes per step through four 256-entry tables in LDS (slicing by four: the four reads of a step do not
+// depend on each other), the tail byte by byte; then one atomic add per record into the slice's sum.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void content_crc_kernel(int32_t n, int32_t n_cont, const int32_t* cont_first,
                                                           const int64_t* base_off, const int32_t* read_len, const uint8_t* bases,
                                                           const uint8_t* quals, uint32_t* crc_sum) {
-    __shared__ uint32_t T[256];
+    __shared__ uint32_t T[4][256];
     {
         uint32_t v = threadIdx.x;
 #pragma unroll
         for (int k = 0; k < 8; k++) v = (v >> 1) ^ (0xEDB88320u & (0u - (v & 1u)));
-        T[threadIdx.x] = v;
+        T[0][threadIdx.x] = v;
+    }
+    __syncthreads();
+    {   // T[k][b] = CRC of byte b followed by k zero bytes
+        uint32_t v = T[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            v = T[0][v & 0xFFu] ^ (v >> 8);
+            T[k][threadIdx.x] = v;
+        }
     }
     __syncthreads();
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -732,7 +742,16 @@ __global__ __launch_bounds__(256) void content_crc_kernel(int32_t n, int32_t n_c
     const uint8_t* p = (which ? quals : bases) + base_off[r];
     const int32_t L = read_len[r];
     uint32_t c = 0xFFFFFFFFu;
-    for (int32_t i = 0; i < L; i++) c = T[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    int32_t i = 0;
+    for (; i + 16 <= L; i += 16) {
+        const U32x4u w = *reinterpret_cast<const U32x4u*>(p + i);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t x = c ^ w.v[k];
+            c = T[3][x & 0xFFu] ^ T[2][(x >> 8) & 0xFFu] ^ T[1][(x >> 16) & 0xFFu] ^ T[0][x >> 24];
+        }
+    }
+    for (; i < L; i++) c = T[0][(c ^ p[i]) & 0xFFu] ^ (c >> 8);
     atomicAdd(&crc_sum[2 * (int64_t)cont_of(cont_first, n_cont, r) + which], ~c);
 }
 
