@@ -237,6 +237,10 @@ struct cramgpu_ctx {
     DevBuf<int64_t> d_series_off, d_series_base;  // ... their offsets, per-container output bases
     PinBuf<int64_t> h_total;
     DevBuf<uint8_t> d_maskws, d_codes25;
+    DevBuf<uint8_t> d_gz_ws;            // cramgpu_gzip_dev: token space of the resident waves
+    hipEvent_t gz_use = nullptr;        //   ... and the order among the calls that share it
+    hipStream_t gz_stream = nullptr;
+    bool gz_valid = false;
     DevBuf<unsigned long long> d_prof;  // CRAMGPU_PROF=1
     bool prof_on = false;
 };
@@ -558,6 +562,8 @@ void cramgpu_close(cramgpu_ctx* c) {
         if (sl.ev) (void)hipEventDestroy(sl.ev);
     }
     if (c->last_use) (void)hipEventDestroy(c->last_use);
+    if (c->gz_use) (void)hipEventDestroy(c->gz_use);
+    c->d_gz_ws.release();
     for (auto& g : c->contigs) g.d.release();
     for (auto& j : c->jobs) {
         j.arena.release();
@@ -1596,10 +1602,23 @@ int32_t cramgpu_gunzip_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, 
 int32_t cramgpu_gzip_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks, int32_t n,
                          int32_t* d_out_len, int32_t bgzf, void* stream) {
     if (!c || n < 0 || (n > 0 && (!d_in || !d_out || !d_blocks || !d_out_len))) return fail(CRAMGPU_E_ARG, "gzip: bad argument");
-    // like gunzip: no scratch of the context, not ordered against the context's other calls
+    // like gunzip, not ordered against the context's other calls (it runs beside the rANS encoder of the same batch on
+    // a stream of its own); its token workspace is ordered among the gzip calls themselves
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(launch_gzip(d_in, d_out, d_blocks, n, d_out_len, bgzf, pick(c, stream)));
+    if (n == 0) return 0;
+    hipStream_t s = pick(c, stream);
+    const int waves = std::min(n, c->n_cu * std::max(1, std::min(env_int("CRAMGPU_GZIP_WAVES_PER_CU", 12), 32)));
+    if (gzip_ws_bytes(waves) > c->d_gz_ws.cap) {
+        if (c->gz_valid) HIPCHK(hipEventSynchronize(c->gz_use));  // the buffer about to be replaced may still be in use
+        HIPCHK(c->d_gz_ws.reserve(gzip_ws_bytes(waves)));
+    }
+    if (!c->gz_use) HIPCHK(hipEventCreateWithFlags(&c->gz_use, hipEventDisableTiming));
+    if (c->gz_valid && c->gz_stream != s) HIPCHK(hipStreamWaitEvent(s, c->gz_use, 0));
+    HIPCHK(launch_gzip(d_in, d_out, d_blocks, n, d_out_len, bgzf, reinterpret_cast<uint32_t*>(c->d_gz_ws.p), waves, s));
+    HIPCHK(hipEventRecord(c->gz_use, s));
+    c->gz_stream = s;
+    c->gz_valid = true;
     return 0;
 }
 

@@ -62,20 +62,20 @@ struct BitW {
     unsigned long long acc;
     int cnt;
 };
-__device__ __forceinline__ void put(BitW& w, uint32_t v, int k) {  // k <= 32, v < 2^k
+__device__ __forceinline__ void put(BitW& w, uint32_t v, int k, bool store = true) {  // k <= 32, v < 2^k
     w.acc |= (unsigned long long)v << w.cnt;
     w.cnt += k;
     if (w.cnt >= 32) {
-        if (w.pos + 4 <= w.cap) reinterpret_cast<W32u*>(w.o + w.pos)->v = (uint32_t)w.acc;
+        if (store && w.pos + 4 <= w.cap) reinterpret_cast<W32u*>(w.o + w.pos)->v = (uint32_t)w.acc;
         w.pos += 4;
         w.acc >>= 32;
         w.cnt -= 32;
     }
 }
-__device__ __forceinline__ void flush_bytes(BitW& w) {  // to a byte boundary, everything out
+__device__ __forceinline__ void flush_bytes(BitW& w, bool store = true) {  // to a byte boundary, everything out
     w.cnt = (w.cnt + 7) & ~7;
     while (w.cnt > 0) {
-        if (w.pos < w.cap) w.o[w.pos] = (uint8_t)w.acc;
+        if (store && w.pos < w.cap) w.o[w.pos] = (uint8_t)w.acc;
         w.pos++;
         w.acc >>= 8;
         w.cnt -= 8;
@@ -529,17 +529,425 @@ __global__ __launch_bounds__(LANES) void gzip_kernel(const uint8_t* in, uint8_t*
     }
 }
 
+
+// =====================================================================================================================
+// A WAVE per member (round 3).  The lane-per-stream kernel above walks one input position per turn through a chain of
+// ~55 dependent instructions; here the 64 lanes take 64 consecutive positions at once:
+//   A  every lane hashes the three bytes at its position, reads the table's candidate (the latest earlier position with
+//      that hash, from the chunks before) and enters its own; it measures the match against that candidate and against
+//      the position right before it (runs of one byte, which a table that only knows earlier chunks would miss); a
+//      scalar walk over the lanes' lengths makes the greedy choice (jumping from match to match with a ballot: a chunk
+//      of literals costs one turn), the lanes a token starts at write it to a token buffer in global memory and count
+//      its symbols with LDS atomics;
+//   B  lane 0 builds the length-limited codes and the header's run-length tokens (the routines of the kernel above);
+//   C  64 tokens at a time: code + extra bits of a token (up to 48 bits), a prefix sum of the bit counts across the
+//      wave, the bits ORed into an LDS staging buffer, whole words out with one store per lane.
+// The member's CRC-32 no longer rides along a serial parse: every lane runs the byte table over its own 64th of the
+// input (front-padded with zeros, which a zero state ignores; the lane holding the first byte starts from 0xFFFFFFFF) and
+// the 64 states are combined in six steps with crc(A || B) = crc(A) * x^(8 |B|) mod P xor crc(B) (zlib's crc32_combine).
+// Every conforming inflater returns the input, as before; the bytes differ from the lane kernel's (other candidates).
+// =====================================================================================================================
+constexpr int kWHashBits = 11, kWHash = 1 << kWHashBits;
+constexpr int kStageWords = 104;  // 31 carried bits + 64 tokens of at most 48 bits = 3103 bits = 97 words, + the spill words
+
+struct WaveLds {
+    uint16_t hash[kWHash];  // position + 1 of the latest occurrence in the block, 0 = none; the counting sort's 256 counters later
+    uint32_t cnt[kAll];     // symbol counts of the block (LDS atomics)
+    uint16_t freq[kAll];    // the counts as build_lengths wants them, then the (bit-reversed) codes
+    uint16_t work[kNL];
+    uint16_t syms[kAll];
+    uint8_t len[kAll];
+    uint16_t clfreq[kNC];
+    uint8_t cllen[kNC];
+    uint16_t num[16];
+    uint32_t stage[kStageWords];
+    uint32_t crc[256];
+    int32_t misc[8];  // hlit, hdist, hclen, nt, header bits
+};
+static_assert(kWHash >= 256, "the match table doubles as the 256 counters of the counting sort");
+
+#ifdef HIP_SIM
+#define GZ_UNI(x) (x)
+#else
+#define GZ_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
+#endif
+
+__device__ __forceinline__ uint32_t mulmodp(uint32_t a, uint32_t b) {  // a * b mod P, x^0 = bit 31 (zlib's multmodp)
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) {
+        p ^= (a & (0x80000000u >> i)) ? b : 0u;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+
+// CRC-32 of p[0, n) by the whole wave (n > 0)
+__device__ uint32_t wave_crc(const uint8_t* p, int32_t n, const uint32_t* T, int lane) {
+    const int32_t seg = (n + 63) / 64, pad = 64 * seg - n;
+    const int32_t lo = lane * seg - pad, hi = lo + seg;
+    uint32_t c = 0;
+    if (hi > 0) {
+        if (lo <= 0) c = 0xFFFFFFFFu;
+        int32_t i = lo > 0 ? lo : 0;
+        for (; i + 4 <= hi; i += 4) {
+            const uint32_t w = ld32(p + i);
+            c = T[(c ^ w) & 255u] ^ (c >> 8);
+            c = T[(c ^ (w >> 8)) & 255u] ^ (c >> 8);
+            c = T[(c ^ (w >> 16)) & 255u] ^ (c >> 8);
+            c = T[(c ^ (w >> 24)) & 255u] ^ (c >> 8);
+        }
+        for (; i < hi; i++) c = T[(c ^ p[i]) & 255u] ^ (c >> 8);
+    }
+    uint32_t xd = 0x80000000u, base = 0x00800000u;  // x^(8 seg): square and multiply from x^8
+    for (int32_t e = seg; e != 0; e >>= 1) {
+        if (e & 1) xd = mulmodp(xd, base);
+        base = mulmodp(base, base);
+    }
+    for (int d = 1; d < 64; d <<= 1) {  // lane l (a multiple of 2 d) <- [l, l + d) followed by [l + d, l + 2 d)
+        const uint32_t other = (uint32_t)__shfl((int)c, (lane + d) & 63);
+        c = mulmodp(xd, c) ^ other;
+        xd = mulmodp(xd, xd);
+    }
+    return (uint32_t)__shfl((int)c, 0) ^ 0xFFFFFFFFu;
+}
+
+__device__ __forceinline__ int match_len(const uint8_t* p, int32_t c, int32_t i, int32_t maxl) {
+    int l = 0;
+    bool go = true;
+    while (go && l + 4 <= maxl) {
+        const uint32_t x = ld32(p + i + l) ^ ld32(p + c + l);
+        if (x != 0) {
+            l += (__ffs((int)x) - 1) >> 3;
+            go = false;
+        } else {
+            l += 4;
+        }
+    }
+    while (go && l < maxl) {
+        if (p[i + l] == p[c + l])
+            l++;
+        else
+            go = false;
+    }
+    return l;
+}
+
+// length 3..258 -> symbol 257..285 + extra bits, distance 1..32768 -> symbol 0..29 + extra bits (RFC 1951 §3.2.5)
+__device__ __forceinline__ void len_symbol(int lm, int& ls, int& leb) {  // lm = length - 3
+    ls = 257 + lm, leb = 0;
+    if (lm >= 8) {
+        const int k = 31 - __clz(lm);
+        leb = k - 2;
+        ls = 261 + 4 * leb + ((lm >> leb) & 3);
+    }
+    if (lm == 255) ls = 285, leb = 0;
+}
+__device__ __forceinline__ void dist_symbol(int dm, int& ds, int& deb) {  // dm = distance - 1
+    ds = dm, deb = 0;
+    if (dm >= 4) {
+        const int k = 31 - __clz(dm);
+        deb = k - 1;
+        ds = 2 * k + ((dm >> deb) & 1);
+    }
+}
+__device__ __forceinline__ int extra_bits_of(int s) {  // of literal / length symbol s < kNL, or distance symbol s - kNL
+    if (s < kNL) return s >= 265 && s < 285 ? (s - 261) >> 2 : 0;
+    const int d = s - kNL;
+    return d >= 4 ? (d >> 1) - 1 : 0;
+}
+
+__device__ void wave_block(const uint8_t* p, int32_t n, bool last, WaveLds& S, uint32_t* tok, BitW& w, int lane) {
+    const bool l0 = lane == 0;
+    for (int i = lane; i < kAll; i += 64) S.cnt[i] = 0;
+    for (int i = lane; i < kWHash; i += 64) S.hash[i] = 0;
+    __syncthreads();
+    // ---- A: matches and tokens ----
+    int32_t ntok = 0, carry = 0;
+    for (int32_t base = 0; base < n; base += 64) {
+        const int32_t i = base + lane;
+        const bool valid = i < n, can = i + 4 <= n;
+        const uint32_t w4 = can ? ld32(p + i) : (valid ? (uint32_t)p[i] : 0u);
+        const int lit = (int)(w4 & 255u);
+        const uint32_t h = ((w4 & 0xFFFFFFu) * 2654435761u) >> (32 - kWHashBits);
+        const int32_t cand = can ? (int32_t)S.hash[h] : 0;
+        __syncthreads();  // every lane has read the table of the chunks before
+        // lanes with one hash: the LAST position stays, whatever order the hardware serves the lanes of one write in
+        // (the bytes of a member must not depend on it): a lane whose entry lost to an earlier position writes again
+        if (can) S.hash[h] = (uint16_t)(i + 1);
+        __syncthreads();
+        for (;;) {
+            const bool again = can && (int32_t)S.hash[h] < i + 1;
+            if (__ballot(again) == 0) break;
+            __syncthreads();
+            if (again) S.hash[h] = (uint16_t)(i + 1);
+            __syncthreads();
+        }
+        int mlen = 0, dist = 0;
+        const int32_t maxl = n - i < 258 ? n - i : 258;
+        if (cand != 0) {
+            const int l = match_len(p, cand - 1, i, maxl);
+            const int d = i - (cand - 1);
+            if (l >= 4 || (l == 3 && d <= 4096)) mlen = l, dist = d;
+        }
+        if (can && i > 0 && dist != 1) {
+            if (((ld32(p + i - 1) ^ w4) & 0xFFFFFFu) == 0) {
+                const int l = match_len(p, i - 1, i, maxl);
+                if (l >= 3 && l >= mlen) mlen = l, dist = 1;
+            }
+        }
+        // the greedy choice: from `carry` (positions the last chunk's final match still covers) literal by literal up to
+        // the next lane that holds a match, then over that match
+        const unsigned long long M = __ballot(mlen > 0);
+        const int nvalid = n - base < 64 ? n - base : 64;
+        unsigned long long starts = 0;
+        int pos = carry;
+        while (pos < nvalid) {
+            const unsigned long long rest = M >> pos;
+            const int t = rest != 0 ? __ffsll((long long)rest) - 1 : 64;
+            const int lit_end = pos + t < nvalid ? pos + t : nvalid;
+            const int k = lit_end - pos;
+            if (k > 0) starts |= (k >= 64 ? ~0ull : ((1ull << k) - 1)) << pos;
+            pos = lit_end;
+            if (pos < nvalid) {
+                starts |= 1ull << pos;
+                pos = GZ_UNI(pos + __shfl(mlen, pos));
+            }
+        }
+        carry = pos - 64;
+        if ((starts >> lane) & 1ull) {
+            const int at = ntok + __popcll(starts & ((1ull << lane) - 1));
+            if (mlen > 0) {
+                int ls, leb, ds, deb;
+                len_symbol(mlen - 3, ls, leb);
+                dist_symbol(dist - 1, ds, deb);
+                tok[at] = 0x80000000u | (uint32_t)(mlen - 3) << 16 | (uint32_t)(dist - 1);
+                atomicAdd(&S.cnt[ls], 1u);
+                atomicAdd(&S.cnt[kNL + ds], 1u);
+            } else {
+                tok[at] = (uint32_t)lit;
+                atomicAdd(&S.cnt[lit], 1u);
+            }
+        }
+        ntok += __popcll(starts);
+    }
+    __syncthreads();
+    if (l0) S.cnt[256] = 1;  // end of block
+    __syncthreads();
+    for (int i = lane; i < kAll; i += 64) S.freq[i] = (uint16_t)S.cnt[i];
+    __syncthreads();
+    // ---- B: codes and header (lane 0; the arrays are the wave's own) ----
+    const Col16 freq{S.freq, 1}, dfreq{S.freq + kNL, 1}, work{S.work, 1}, syms{S.syms, 1}, clfreq{S.clfreq, 1}, num{S.num, 1};
+    const Col8 len{S.len, 1}, dlen{S.len + kNL, 1}, cllen{S.cllen, 1};
+    if (l0) {
+        build_lengths(freq, kNL, 15, len, work, syms, num, Col16{S.hash, 1});
+        build_lengths(dfreq, kND, 15, dlen, work, syms, num, Col16{nullptr, 0});
+        int hlit = kNL, hdist = kND;
+        while (hlit > 257 && S.len[hlit - 1] == 0) hlit--;
+        while (hdist > 1 && dlen[hdist - 1] == 0) hdist--;
+        const int total = hlit + hdist;
+        for (int s = 0; s < kNC; s++) S.clfreq[s] = 0;
+        int nt = 0;
+        uint32_t hdr = 0;
+        auto seq = [&](int i) -> int { return i < hlit ? S.len[i] : S.len[kNL + i - hlit]; };
+        for (int i = 0; i < total;) {
+            const int v = seq(i);
+            int run = 1;
+            while (i + run < total && seq(i + run) == v) run++;
+            i += run;
+            if (v != 0) {
+                S.syms[nt++] = (uint16_t)v;
+                S.clfreq[v] = (uint16_t)(S.clfreq[v] + 1);
+                run--;
+            }
+            while (run > 0) {
+                int sym, ext = 0, take = 1;
+                if (v == 0 && run >= 11) {
+                    take = run < 138 ? run : 138;
+                    sym = 18, ext = take - 11, hdr += 7;
+                } else if (v == 0 && run >= 3) {
+                    take = run;
+                    sym = 17, ext = take - 3, hdr += 3;
+                } else if (v != 0 && run >= 3) {
+                    take = run < 6 ? run : 6;
+                    sym = 16, ext = take - 3, hdr += 2;
+                } else {
+                    sym = v;
+                }
+                S.syms[nt++] = (uint16_t)(sym | ext << 5);
+                S.clfreq[sym] = (uint16_t)(S.clfreq[sym] + 1);
+                run -= take;
+            }
+        }
+        const int mcl = build_lengths(clfreq, kNC, 7, cllen, work, Col16{S.work + kNC, 1}, num, Col16{nullptr, 0});
+        if (mcl == 1) {  // see deflate_block
+            const int other = S.cllen[0] != 0 ? 1 : 0;
+            S.cllen[other] = 1;
+        }
+        for (int s = 0; s < kNC; s++) hdr += (uint32_t)S.clfreq[s] * S.cllen[s];
+        int hclen = kNC;
+        while (hclen > 4 && S.cllen[cl_order(hclen - 1)] == 0) hclen--;
+        hdr += 3 + 14 + 3 * (uint32_t)hclen;
+        S.misc[0] = hlit, S.misc[1] = hdist, S.misc[2] = hclen, S.misc[3] = nt, S.misc[4] = (int32_t)hdr;
+    }
+    __syncthreads();
+    uint32_t body = 0;
+    for (int s = lane; s < kAll; s += 64) body += S.cnt[s] * (uint32_t)(S.len[s] + extra_bits_of(s));
+    for (int d = 32; d > 0; d >>= 1) body += (uint32_t)__shfl_xor((int)body, d);
+    const int hlit = S.misc[0], hdist = S.misc[1], hclen = S.misc[2], nt = S.misc[3];
+    const uint32_t hdr = (uint32_t)S.misc[4];
+    const uint32_t stored_bits = 3 + 7 + 32 + 8 * (uint32_t)n;
+    if (hdr + body >= stored_bits) {
+        // stored block (RFC 1951 §3.2.4): header bits, pad to a byte, LEN, ~LEN, then the bytes, copied by the wave
+        put(w, last ? 1u : 0u, 3, l0);
+        flush_bytes(w, l0);
+        put(w, (uint32_t)n | (~(uint32_t)n << 16), 32, l0);  // the accumulator is empty behind it
+        for (int32_t i = lane; i < n; i += 64)
+            if (w.pos + i < w.cap) w.o[w.pos + i] = p[i];
+        w.pos += n;
+        __syncthreads();
+        return;
+    }
+    if (l0) {
+        assign_codes(len, kNL, freq, num);
+        assign_codes(dlen, kND, dfreq, num);
+        assign_codes(cllen, kNC, clfreq, num);
+    }
+    __syncthreads();
+    put(w, (last ? 1u : 0u) | 2u << 1, 3, l0);
+    put(w, (uint32_t)(hlit - 257) | (uint32_t)(hdist - 1) << 5 | (uint32_t)(hclen - 4) << 10, 14, l0);
+    for (int i = 0; i < hclen; i++) put(w, S.cllen[cl_order(i)], 3, l0);
+    for (int t = 0; t < nt; t++) {
+        const int tk = S.syms[t], sym = tk & 31, ext = tk >> 5;
+        put(w, S.clfreq[sym], S.cllen[sym], l0);
+        if (sym == 16) put(w, (uint32_t)ext, 2, l0);
+        if (sym == 17) put(w, (uint32_t)ext, 3, l0);
+        if (sym == 18) put(w, (uint32_t)ext, 7, l0);
+    }
+    // ---- C: the codes of 64 tokens at a time ----
+    for (int32_t tb = 0; tb < ntok; tb += 64) {
+        const int32_t t = tb + lane;
+        unsigned long long v = 0;
+        int nb = 0;
+        if (t < ntok) {
+            const uint32_t tk = tok[t];
+            if (tk >> 31) {
+                const int lm = (int)((tk >> 16) & 255u), dm = (int)(tk & 0x7FFFu);
+                int ls, leb, ds, deb;
+                len_symbol(lm, ls, leb);
+                dist_symbol(dm, ds, deb);
+                const int ll = S.len[ls], dl = S.len[kNL + ds];
+                v = (unsigned long long)S.freq[ls] | (unsigned long long)(lm & ((1 << leb) - 1)) << ll |
+                    (unsigned long long)S.freq[kNL + ds] << (ll + leb) | (unsigned long long)(dm & ((1 << deb) - 1)) << (ll + leb + dl);
+                nb = ll + leb + dl + deb;
+            } else {
+                v = S.freq[tk];
+                nb = S.len[tk];
+            }
+        }
+        int incl = nb;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int x = __shfl_up(incl, d);
+            if (lane >= d) incl += x;
+        }
+        const int total = __shfl(incl, 63);
+        const int off = w.cnt + incl - nb;
+        const int full = (w.cnt + total) >> 5;
+        for (int j = lane; j < full + 3 && j < kStageWords; j += 64) S.stage[j] = 0;
+        __syncthreads();
+        if (l0 && w.cnt != 0) atomicOr(&S.stage[0], (uint32_t)w.acc);
+        if (nb != 0) {
+            const int wi = off >> 5, sh = off & 31;
+            const unsigned long long lo = v << sh;
+            atomicOr(&S.stage[wi], (uint32_t)lo);
+            if ((lo >> 32) != 0) atomicOr(&S.stage[wi + 1], (uint32_t)(lo >> 32));
+            if (sh != 0 && (v >> (64 - sh)) != 0) atomicOr(&S.stage[wi + 2], (uint32_t)(v >> (64 - sh)));
+        }
+        __syncthreads();
+        for (int j = lane; j < full; j += 64)
+            if (w.pos + 4 * j + 4 <= w.cap) reinterpret_cast<W32u*>(w.o + w.pos + 4 * j)->v = S.stage[j];
+        w.acc = S.stage[full];
+        w.cnt = (w.cnt + total) & 31;
+        w.pos += 4 * full;
+        __syncthreads();
+    }
+    put(w, S.freq[256], S.len[256], l0);
+}
+
+__global__ __launch_bounds__(64) void gzip_wave_kernel(const uint8_t* in, uint8_t* out, const cramgpu_block* desc, int32_t n,
+                                                       int32_t* out_len, int32_t bgzf, uint32_t* ws) {
+    __shared__ WaveLds S;
+    const int lane = (int)threadIdx.x;
+    const bool l0 = lane == 0;
+    for (int i = lane; i < 256; i += 64) {  // CRC-32 (IEEE 802.3, reflected 0xEDB88320) byte table
+        uint32_t c = (uint32_t)i;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        S.crc[i] = c;
+    }
+    __syncthreads();
+    uint32_t* tok = ws + (size_t)blockIdx.x * kBlock;
+    for (int32_t k = (int32_t)blockIdx.x; k < n; k += (int32_t)gridDim.x) {
+        const cramgpu_block D = desc[k];
+        const int32_t len = D.in_len;
+        if (len < 0 || D.out_cap < 0) {
+            if (l0) out_len[k] = CRAMGPU_E_ARG;
+            continue;
+        }
+        const uint8_t* p = in + D.in_off;
+        BitW w{out + D.out_off, 0, D.out_cap, 0ull, 0};
+        put(w, 0x00088B1Fu | (bgzf ? 4u << 24 : 0u), 32, l0);  // member header: see gzip_kernel
+        put(w, 0u, 32, l0);
+        put(w, 0xFF00u, 16, l0);
+        if (bgzf) {
+            put(w, 6u | (uint32_t)'B' << 16 | (uint32_t)'C' << 24, 32, l0);
+            put(w, 2u, 32, l0);
+        }
+        uint32_t crc = 0;
+        if (len == 0) {
+            put(w, 3u, 10, l0);
+        } else {
+            crc = wave_crc(p, len, S.crc, lane);
+            for (int32_t at = 0; at < len; at += kBlock) {
+                const int32_t m = len - at < kBlock ? len - at : kBlock;
+                wave_block(p + at, m, at + m >= len, S, tok, w, lane);
+            }
+        }
+        flush_bytes(w, l0);
+        put(w, crc, 32, l0);
+        put(w, (uint32_t)len, 32, l0);
+        flush_bytes(w, l0);
+        int32_t rc = w.pos;
+        if (w.pos > w.cap) rc = CRAMGPU_E_OUT_TOO_SMALL;
+        if (bgzf && rc > 0) {
+            if (rc > 65536) {
+                rc = CRAMGPU_E_OUT_TOO_SMALL;
+            } else if (l0) {
+                w.o[16] = (uint8_t)(rc - 1);
+                w.o[17] = (uint8_t)((rc - 1) >> 8);
+            }
+        }
+        if (l0) out_len[k] = rc;
+        __syncthreads();  // the member's last stores (lane 0) before the next member's tables are cleared
+    }
+}
+
 }  // namespace
 
+size_t gzip_ws_bytes(int n_waves) { return (size_t)n_waves * kBlock * sizeof(uint32_t); }
+
 hipError_t launch_gzip(const uint8_t* in, uint8_t* out, const cramgpu_block* d_desc, int32_t n, int32_t* out_len, int32_t bgzf,
-                       hipStream_t s) {
+                       uint32_t* ws, int n_waves, hipStream_t s) {
     if (n == 0) return hipSuccess;
     static const int forced = [] {
         const char* e = getenv("CRAMGPU_GZIP_LANES");
         return e ? atoi(e) : 0;
     }();
-    // streams per wave: 2 (352 ms for 20 000 BGZF blocks), 4 (451), 8 (442) — the fewer streams diverge in a wave the better,
-    // as in the gunzip kernel
+    if (ws != nullptr && n_waves > 0 && !(forced == 2 || forced == 4 || forced == 8)) {
+        // a wave per member, resident waves striding over the members (the caller sorts them longest first)
+        hipLaunchKernelGGL(gzip_wave_kernel, dim3((unsigned)(n < n_waves ? n : n_waves)), dim3(64), 0, s, in, out, d_desc, n, out_len,
+                           bgzf, ws);
+        return hipGetLastError();
+    }
+    // the lane-per-stream kernel of round 2 (CRAMGPU_GZIP_LANES = 2 / 4 / 8 streams per wave)
     const int lanes = forced == 2 || forced == 4 || forced == 8 ? forced : 2;
 #define GZIP_LAUNCH(L) \
     hipLaunchKernelGGL(gzip_kernel<L>, dim3((unsigned)((n + L - 1) / L)), dim3(L), 0, s, in, out, d_desc, n, out_len, bgzf)

@@ -113,4 +113,6 @@ hipError_t launch_bam_decode(int32_t n, const uint8_t* bam, const int64_t* rec_o
 hipError_t launch_slice_md5(int32_t n, const uint8_t* ref, const cramgpu_refwin* win, const int32_t* start, const int32_t* span,
                             uint8_t* md5, hipStream_t s);
 hipError_t launch_gunzip(const uint8_t* in, uint8_t* out, const cramgpu_block* d_desc, int32_t n, int32_t* out_len, hipStream_t s);
-hipError_t launch_gzip(const uint8_t* in, uint8_t* out, const cramgpu_block* d_desc, int32_t n, int32_t* out_len, int32_t bgzf, hipStream_t s);
+hipError_t launch_gzip(const uint8_t* in, uint8_t* out, const cramgpu_block* d_desc, int32_t n, int32_t* out_len, int32_t bgzf,
+                       uint32_t* ws, int n_waves, hipStream_t s);  // ws: gzip_ws_bytes(n_waves) of token space (nullptr: lane-per-stream kernel)
+size_t gzip_ws_bytes(int n_waves);

@@ -183,6 +183,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     return (s < 0 || !enabled) ? old : r;
 }
 inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline uint32_t atomicOr(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 inline uint32_t atomicMin(uint32_t* p, uint32_t v) {
     uint32_t o = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (v < o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
