@@ -548,6 +548,7 @@ __global__ __launch_bounds__(LANES) void gzip_kernel(const uint8_t* in, uint8_t*
 // Every conforming inflater returns the input, as before; the bytes differ from the lane kernel's (other candidates).
 // =====================================================================================================================
 constexpr int kWHashBits = 11, kWHash = 1 << kWHashBits;
+constexpr int kNear = 8;  // at most 8: the near candidates come out of a 16-byte register window
 constexpr int kStageWords = 104;  // 31 carried bits + 64 tokens of at most 48 bits = 3103 bits = 97 words, + the spill words
 
 struct WaveLds {
@@ -611,8 +612,7 @@ __device__ uint32_t wave_crc(const uint8_t* p, int32_t n, const uint32_t* T, int
     return (uint32_t)__shfl((int)c, 0) ^ 0xFFFFFFFFu;
 }
 
-__device__ __forceinline__ int match_len(const uint8_t* p, int32_t c, int32_t i, int32_t maxl) {
-    int l = 0;
+__device__ __forceinline__ int match_len(const uint8_t* p, int32_t c, int32_t i, int32_t maxl, int l = 0) {  // l bytes are known to agree
     bool go = true;
     while (go && l + 4 <= maxl) {
         const uint32_t x = ld32(p + i + l) ^ ld32(p + c + l);
@@ -682,18 +682,41 @@ __device__ void wave_block(const uint8_t* p, int32_t n, bool last, WaveLds& S, u
             if (again) S.hash[h] = (uint16_t)(i + 1);
             __syncthreads();
         }
+        // Candidates: the positions right before this one, which the table cannot know (they are this chunk's) — distances
+        // 1..kNear, nearest first: runs of one byte, values of a fixed width — and the table's.  Each is measured against the
+        // eight bytes at the position with one unaligned load, no loop; only the winner is extended beyond eight bytes.
         int mlen = 0, dist = 0;
         const int32_t maxl = n - i < 258 ? n - i : 258;
-        if (cand != 0) {
-            const int l = match_len(p, cand - 1, i, maxl);
-            const int d = i - (cand - 1);
-            if (l >= 4 || (l == 3 && d <= 4096)) mlen = l, dist = d;
-        }
-        if (can && i > 0 && dist != 1) {
-            if (((ld32(p + i - 1) ^ w4) & 0xFFFFFFu) == 0) {
-                const int l = match_len(p, i - 1, i, maxl);
-                if (l >= 3 && l >= mlen) mlen = l, dist = 1;
+        if (can) {
+            const bool can8 = i + 8 <= n;
+            const unsigned long long w8 = can8 ? (unsigned long long)w4 | (unsigned long long)ld32(p + i + 4) << 32 : 0ull;
+            auto measure = [&](unsigned long long c8, int d) {  // c8: the eight bytes at i - d
+                int l;
+                if (can8) {
+                    const unsigned long long x = c8 ^ w8;
+                    l = x != 0 ? (__ffsll((long long)x) - 1) >> 3 : 8;
+                } else {
+                    l = (((uint32_t)c8 ^ w4) & 0xFFFFFFu) == 0 ? 3 : 0;
+                }
+                if (l >= 3 && l > mlen) mlen = l, dist = d;
+            };
+            // the eight bytes before the position and the eight at it are a 16-byte window that holds every near candidate
+            unsigned long long prev8 = 0;
+            if (i >= 8) {
+                prev8 = (unsigned long long)ld32(p + i - 8) | (unsigned long long)ld32(p + i - 4) << 32;
+            } else {
+                for (int k = 0; k < i; k++) prev8 |= (unsigned long long)p[k] << (8 * (8 - i + k));
             }
+            const unsigned long long cur8 = can8 ? w8 : (unsigned long long)w4;
+#pragma unroll
+            for (int d = 1; d <= kNear; d++)
+                if (i >= d) measure(d == 8 ? prev8 : (prev8 >> (8 * (8 - d))) | (cur8 << (8 * d)), d);
+            if (cand != 0) {
+                const int32_t c = cand - 1;
+                measure(can8 ? (unsigned long long)ld32(p + c) | (unsigned long long)ld32(p + c + 4) << 32 : (unsigned long long)ld32(p + c), i - c);
+            }
+            if (mlen != 0 && (mlen == 8 || !can8)) mlen = match_len(p, i - dist, i, maxl, mlen);
+            if (mlen == 3 && dist > 4096) mlen = 0, dist = 0;  // zlib's TOO_FAR: such a match costs more bits than three literals
         }
         // the greedy choice: from `carry` (positions the last chunk's final match still covers) literal by literal up to
         // the next lane that holds a match, then over that match
