@@ -307,13 +307,23 @@ class Step:
         return d[np.argsort(-pl, kind="stable")], int(cap.sum())
 
     def run_full(self, timed):
-        """K3 -> F3 -> #setMateInfo -> W -> (K1 beside Z: the GZIP series written as gzip members on a second stream) ->
-        slice reference MD5 -> ContentDigests -> gather, one region."""
+        """K3 -> F3 -> #setMateInfo -> W -> Z (the GZIP series as gzip members) -> K1 -> gather, with the slice reference MD5s
+        and the ContentDigests on a second stream beside all of it; one region."""
         w, L = self.w, _lib.lib()
         reads, cols = w["reads"], w["cols"]
         main = torch.cuda.current_stream()
         if timed:
             self.ev_full[0].record()
+        # slice MD5 and content digests read the reads and the reference only and use no LDS: on a second stream from the
+        # head of the region, they fill the issue slots the other kernels (at last the encoder's chains) leave
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            sd = self.side.cuda_stream
+            _lib.check(L.cramgpu_slice_md5_dev(self.eng.handle, w["n_cont"], w["ref"].data_ptr(), self.sl_win.data_ptr(),
+                                               self.sl_start.data_ptr(), self.sl_span.data_ptr(), self.md5.data_ptr(), sd))
+            _lib.check(L.cramgpu_content_digests_dev(self.eng.handle, reads.n, w["n_cont"], self.cont_first.data_ptr(),
+                                                     reads.base_off.data_ptr(), reads.read_len.data_ptr(), reads.bases.data_ptr(),
+                                                     reads.quals.data_ptr(), self.crc.data_ptr(), sd))
         self.hist.zero_()
         rs_, fs_ = reads.struct(), self.feats.struct()
         self.feats.count = int(_lib.check(L.cramgpu_extract_features_dev(self.eng.handle, C.byref(rs_), w["ref"].data_ptr(), C.byref(fs_),
@@ -341,15 +351,10 @@ class Step:
         self.gz_pin[:gd.size] = torch.from_numpy(gd.view(np.uint8).reshape(gd.size, -1))
         self.gz_desc[:gd.size].copy_(self.gz_pin[:gd.size], non_blocking=True)
         self.n_gz, self.gz_plan = int(gd.size), gd
-        self.side.wait_stream(main)
+        # Z before K1 on the same stream: the encoder's resident workgroups hold the whole LDS of every CU, a gzip wave
+        # (9.5 KiB of tables) finds no room beside them and would only start as they retire
+        self.eng.gzip_dev(self.writer.arena, self.gz_out, self.gz_desc, self.n_gz, self.gz_len)
         self.eng.encode_dev(base, self.d_out, blk, w["n_blocks"], self.d_len, self.d_pos)
-        with torch.cuda.stream(self.side):  # launched after K1: the chain waves take their SIMDs first, Z fills the rest
-            self.eng.gzip_dev(self.writer.arena, self.gz_out, self.gz_desc, self.n_gz, self.gz_len)
-        _lib.check(L.cramgpu_slice_md5_dev(self.eng.handle, w["n_cont"], w["ref"].data_ptr(), self.sl_win.data_ptr(),
-                                           self.sl_start.data_ptr(), self.sl_span.data_ptr(), self.md5.data_ptr(), main.cuda_stream))
-        _lib.check(L.cramgpu_content_digests_dev(self.eng.handle, reads.n, w["n_cont"], self.cont_first.data_ptr(),
-                                                 reads.base_off.data_ptr(), reads.read_len.data_ptr(), reads.bases.data_ptr(),
-                                                 reads.quals.data_ptr(), self.crc.data_ptr(), main.cuda_stream))
         self.eng.gather_dev(self.d_out, self.d_pos, self.d_len, w["n_blocks"], w["max_cap"], self.d_pack, self.d_pack_off)
         main.wait_stream(self.side)
         if timed:
@@ -1472,8 +1477,8 @@ def main(argv=None, backend_factory=GpuBackend):
             ef = float(np.mean(step.full_ms))
             extra["encode_full"] = dict(
                 workload="one region per step, CramSerilization.java:108-200 per container: K3 -> F3 -> setMateInfo (unique read "
-                         "names: every record detached) -> W -> K1 beside Z (the %d non-rANS series as gzip members, pieces of 8 KiB) "
-                         "-> slice reference MD5 -> ContentDigests BD / SD -> gather" % len(step.rest),
+                         "names: every record detached) -> W -> Z (the %d non-rANS series as gzip members, pieces of 8 KiB) -> K1 -> "
+                         "gather; slice reference MD5 and ContentDigests BD / SD on a second stream beside them" % len(step.rest),
                 ms=ef, value=w["raw_bytes"] / ef / 1e3, unit="MB/s", reads_per_s=a.reads / ef * 1e3, **step.verify_full())
             dec.run_full(False)
             for _ in range(a.steps):

@@ -1535,10 +1535,11 @@ int32_t cramgpu_content_digests_dev(cramgpu_ctx* c, int32_t n_reads, int32_t n_c
                                     const uint8_t* d_quals, uint32_t* d_crc, void* stream) {
     if (!c || n_reads < 0 || n_cont < 1 || !d_cont_first || !d_base_off || !d_read_len || !d_bases || !d_quals || !d_crc)
         return fail(CRAMGPU_E_ARG, "content_digests: bad argument");
+    // no scratch of the context is touched: not ordered against the context's other calls, so that a caller may run it on
+    // a stream of its own beside them (bench.py encode_full: beside the rANS encoder)
     std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
-    if (int rc = enter(c, s)) return rc;
-    CallScope scope{c, s};
     HIPCHK(launch_content_crc(n_reads, n_cont, d_cont_first, d_base_off, d_read_len, d_bases, d_quals, d_crc, s));
     return 0;
 }
@@ -1580,10 +1581,10 @@ int32_t cramgpu_bam_decode_dev(cramgpu_ctx* c, int32_t n_reads, const uint8_t* d
 int32_t cramgpu_slice_md5_dev(cramgpu_ctx* c, int32_t n_slices, const uint8_t* d_ref, const cramgpu_refwin* d_wins,
                               const int32_t* d_start, const int32_t* d_span, uint8_t* d_md5, void* stream) {
     if (!c || n_slices < 0 || !d_ref || !d_wins || !d_start || !d_span || !d_md5) return fail(CRAMGPU_E_ARG, "slice_md5: bad argument");
+    // like the content digests: no scratch, not ordered against the context's other calls
     std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
     hipStream_t s = pick(c, stream);
-    if (int rc = enter(c, s)) return rc;
-    CallScope scope{c, s};
     HIPCHK(launch_slice_md5(n_slices, d_ref, d_wins, d_start, d_span, d_md5, s));
     return 0;
 }

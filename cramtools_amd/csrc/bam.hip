@@ -738,21 +738,36 @@ __global__ __launch_bounds__(256) void content_crc_kernel(int32_t n, int32_t n_c
     __syncthreads();
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int32_t r = (int32_t)(id >> 1), which = (int32_t)(id & 1);
-    if (r >= n) return;
-    const uint8_t* p = (which ? quals : bases) + base_off[r];
-    const int32_t L = read_len[r];
-    uint32_t c = 0xFFFFFFFFu;
-    int32_t i = 0;
-    for (; i + 16 <= L; i += 16) {
-        const U32x4u w = *reinterpret_cast<const U32x4u*>(p + i);
+    uint32_t v = 0;  // the record's CRC (nothing for the lanes behind the last record)
+    int32_t cont = -1;
+    if (r < n) {
+        const uint8_t* p = (which ? quals : bases) + base_off[r];
+        const int32_t L = read_len[r];
+        uint32_t c = 0xFFFFFFFFu;
+        int32_t i = 0;
+        for (; i + 16 <= L; i += 16) {
+            const U32x4u w = *reinterpret_cast<const U32x4u*>(p + i);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t x = c ^ w.v[k];
-            c = T[3][x & 0xFFu] ^ T[2][(x >> 8) & 0xFFu] ^ T[1][(x >> 16) & 0xFFu] ^ T[0][x >> 24];
+            for (int k = 0; k < 4; k++) {
+                const uint32_t x = c ^ w.v[k];
+                c = T[3][x & 0xFFu] ^ T[2][(x >> 8) & 0xFFu] ^ T[1][(x >> 16) & 0xFFu] ^ T[0][x >> 24];
+            }
         }
+        for (; i < L; i++) c = T[0][(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+        v = ~c;
+        cont = cont_of(cont_first, n_cont, r);
     }
-    for (; i < L; i++) c = T[0][(c ^ p[i]) & 0xFFu] ^ (c >> 8);
-    atomicAdd(&crc_sum[2 * (int64_t)cont_of(cont_first, n_cont, r) + which], ~c);
+    // A wave holds 32 consecutive records, nearly always of one container: its 64 values are summed across the lanes of a
+    // parity first (bases in the even lanes, scores in the odd ones) and leave as TWO atomic adds.  One add per record made
+    // every wave of the launch queue up on the two words of the container in hand: 13.6 ms for configs[1], 12 of them waiting.
+    const int32_t c0 = __shfl(cont, 0);
+    const bool same = __ballot(cont != c0 && cont >= 0) == 0 && c0 >= 0;
+    if (same) {
+        for (int d = 2; d < 64; d <<= 1) v += (uint32_t)__shfl_xor((int)v, d);
+        if ((threadIdx.x & 63) < 2) atomicAdd(&crc_sum[2 * (int64_t)c0 + which], v);
+    } else if (cont >= 0) {
+        atomicAdd(&crc_sum[2 * (int64_t)cont + which], v);
+    }
 }
 
 inline dim3 grid1(int64_t n, int per_block) { return dim3((unsigned)((n + per_block - 1) / per_block > 0 ? (n + per_block - 1) / per_block : 1)); }
