@@ -70,13 +70,16 @@ class RecordCols(C.Structure):
     _fields_ = [("bam_flags", C.c_void_p), ("comp_flags", C.c_void_p), ("ref_id", C.c_void_p), ("read_group", C.c_void_p),
                 ("mate_flags", C.c_void_p), ("mate_ref", C.c_void_p), ("mate_start", C.c_void_p), ("tlen", C.c_void_p),
                 ("next_frag", C.c_void_p), ("tag_list", C.c_void_p), ("cont_multiref", C.c_void_p),
-                ("cont_ap_base", C.c_void_p), ("ap_delta", C.c_int32), ("flags", C.c_int32)]
+                ("cont_ap_base", C.c_void_p), ("ap_delta", C.c_int32), ("flags", C.c_int32),
+                ("names", C.c_void_p), ("name_off", C.c_void_p), ("name_len", C.c_void_p), ("capture_names", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class ReadOut(C.Structure):
     _fields_ = [("read_len", C.c_void_p), ("aln_start", C.c_void_p), ("mapq", C.c_void_p), ("base_off", C.c_void_p),
                 ("bases", C.c_void_p), ("quals", C.c_void_p), ("bases_cap", C.c_int64), ("seq", C.c_void_p),
-                ("seq_off", C.c_void_p), ("seq_cap", C.c_int64), ("rflags", C.c_void_p)]
+                ("seq_off", C.c_void_p), ("seq_cap", C.c_int64), ("rflags", C.c_void_p), ("name_off", C.c_void_p),
+                ("name_len", C.c_void_p)]
 
 
 N_SERIES = 30

@@ -101,6 +101,9 @@ __device__ __forceinline__ void record_sizes(const WArgs& A, int32_t r, bool mul
     z.v[CRAMGPU_DS_RL] = itf8_len(L);
     z.v[CRAMGPU_DS_AP] = itf8_len((uint32_t)(A.c.ap_delta ? A.r.aln_start[r] - prev_start : A.r.aln_start[r]));
     z.v[CRAMGPU_DS_RG] = itf8_len((uint32_t)A.c.read_group[r]);
+    // Writer#write: `if (captureReadNames) RN` in front of the mate block, `if (!captureReadNames) RN` inside it
+    if (A.c.names != nullptr && (A.c.capture_names || (cf & CRAMGPU_CF_DETACHED)))
+        z.v[CRAMGPU_DS_RN] = (uint32_t)(A.c.name_len[r] > 0 ? A.c.name_len[r] : 0) + 1u;
     if (cf & CRAMGPU_CF_DETACHED) {
         z.v[CRAMGPU_DS_MF] = itf8_len((uint32_t)A.c.mate_flags[r]);
         z.v[CRAMGPU_DS_NS] = itf8_len((uint32_t)A.c.mate_ref[r]);
@@ -310,6 +313,13 @@ __global__ __launch_bounds__(kTile) void series_write_kernel(WArgs A) {
             itf8_put(SP(CRAMGPU_DS_RL), L);
             itf8_put(SP(CRAMGPU_DS_AP), (uint32_t)(A.c.ap_delta ? A.r.aln_start[r] - prev_start : A.r.aln_start[r]));
             itf8_put(SP(CRAMGPU_DS_RG), (uint32_t)A.c.read_group[r]);
+            if (A.c.names != nullptr && (A.c.capture_names || (cf & CRAMGPU_CF_DETACHED))) {
+                uint8_t* rn = SP(CRAMGPU_DS_RN);
+                const uint8_t* src = A.c.names + A.c.name_off[r];
+                const int32_t nl = A.c.name_len[r] > 0 ? A.c.name_len[r] : 0;
+                for (int32_t i = 0; i < nl; i++) rn[i] = src[i];
+                rn[nl] = '\t';
+            }
             if (cf & CRAMGPU_CF_DETACHED) {
                 itf8_put(SP(CRAMGPU_DS_MF), (uint32_t)A.c.mate_flags[r]);
                 itf8_put(SP(CRAMGPU_DS_NS), (uint32_t)A.c.mate_ref[r]);
@@ -439,7 +449,7 @@ __device__ __forceinline__ bool is_int_series(int k) {
            k == CRAMGPU_DS_NF || k == CRAMGPU_DS_TL || k == CRAMGPU_DS_FN || k == CRAMGPU_DS_FP || k == CRAMGPU_DS_DL ||
            k == CRAMGPU_DS_RS || k == CRAMGPU_DS_HC || k == CRAMGPU_DS_PD || k == CRAMGPU_DS_MQ;
 }
-__device__ __forceinline__ bool is_item_series(int k) { return k == CRAMGPU_DS_IN || k == CRAMGPU_DS_SC; }
+__device__ __forceinline__ bool is_item_series(int k) { return k == CRAMGPU_DS_IN || k == CRAMGPU_DS_SC || k == CRAMGPU_DS_RN; }
 
 // R0: workspace slots: a series of n bytes holds at most n values (n + 1 item starts)
 __global__ __launch_bounds__(1024) void series_ws_layout_kernel(RArgs A) {
@@ -812,6 +822,12 @@ __global__ __launch_bounds__(kTile) void series_read_kernel(RArgs A) {
                      (det && (i_det >= vcnt[CRAMGPU_DS_NS] || i_det >= vcnt[CRAMGPU_DS_NP] || i_det >= vcnt[CRAMGPU_DS_TS])) ||
                      (down && i_down >= vcnt[CRAMGPU_DS_NF])))
             bad = true;
+        // the record's name (ReaderToBAM.java:86-93): every record's when names are captured, a detached record's otherwise;
+        // a container written without names has an empty RN stream and none of its records carries one
+        const bool rn_any = A.c.capture_names || vcnt[CRAMGPU_DS_RN] != 0;
+        const bool named = live && rn_any && (A.c.capture_names || det);
+        const int64_t i_name = A.c.capture_names ? (int64_t)k : i_det;
+        if (named && i_name >= vcnt[CRAMGPU_DS_RN]) bad = true;
         // sequence bytes of the record's I / S features
         uint32_t nseq = 0;
         if (live && !bad) {
@@ -848,6 +864,12 @@ __global__ __launch_bounds__(kTile) void series_read_kernel(RArgs A) {
                                           ((cf & CRAMGPU_CF_UNKNOWN_BASES) ? CRAMGPU_RF_UNKNOWN_BASES : 0) |
                                           ((cf & CRAMGPU_CF_FORCE_PRESERVE_QS) ? CRAMGPU_RF_FORCE_QS : 0));
             A.o.seq_off[r] = seq0;
+            if (A.o.name_off != nullptr && A.o.name_len != nullptr) {
+                const bool has = named && ok;
+                const int32_t s0 = has ? VAL(CRAMGPU_DS_RN, i_name) : 0, s1 = has ? VAL(CRAMGPU_DS_RN, i_name + 1) : 0;
+                A.o.name_off[r] = has ? soff[CRAMGPU_DS_RN] + s0 : 0;
+                A.o.name_len[r] = has ? s1 - s0 - 1 : -1;
+            }
             A.f.off[r] = base_f + f_loc;
             if (ok && boff + L <= A.o.bases_cap) {
                 if (mapped && base_f + f_loc + nfeat <= A.f.cap && seq0 + nseq <= A.o.seq_cap) {
@@ -937,7 +959,8 @@ __global__ __launch_bounds__(kTile) void series_read_kernel(RArgs A) {
             run2[T_FEAT] != vcnt[CRAMGPU_DS_FP] || run2[T_BA] != slen[CRAMGPU_DS_BA] || run2[T_QS] != slen[CRAMGPU_DS_QS] ||
             run2[T_X] != slen[CRAMGPU_DS_BS] || run2[T_D] != vcnt[CRAMGPU_DS_DL] || run2[T_N] != vcnt[CRAMGPU_DS_RS] ||
             run2[T_H] != vcnt[CRAMGPU_DS_HC] || run2[T_P] != vcnt[CRAMGPU_DS_PD] || run2[T_I] != vcnt[CRAMGPU_DS_IN] ||
-            run2[T_S] != vcnt[CRAMGPU_DS_SC])
+            run2[T_S] != vcnt[CRAMGPU_DS_SC] ||
+            ((A.c.capture_names || vcnt[CRAMGPU_DS_RN] != 0) && (A.c.capture_names ? (long long)n_rec : run1[S_DET]) != vcnt[CRAMGPU_DS_RN]))
             *A.status = CRAMGPU_E_CORRUPT;
     }
 }

@@ -154,9 +154,13 @@ class RecordColumns:
     """The CramCompressionRecord fields that reads and features do not hold, as device int32 arrays
     (cramgpu_record_cols): what htsjdk!encoding/writer/Writer#write reads besides bases, scores and features."""
 
-    def __init__(self, device, n_reads, multiref=None, ap_base=None, ap_delta=True, alias_qs=False, **cols):
+    def __init__(self, device, n_reads, multiref=None, ap_base=None, ap_delta=True, alias_qs=False, names=None, name_off=None,
+                 name_len=None, capture_names=False, **cols):
+        """names / name_off / name_len: device tensors (uint8 bytes the names lie in, int64 [n], int32 [n]) — the writer
+        then fills RN (every record's name with capture_names, the detached records' otherwise)."""
         torch = _torch()
         self.device, self.n = device, n_reads
+        self.names, self.name_off, self.name_len, self.capture_names = names, name_off, name_len, bool(capture_names)
         for k in RECORD_COLS:
             v = cols.get(k)
             setattr(self, k, _dev(v, torch.int32, device) if v is not None else torch.zeros(n_reads, dtype=torch.int32, device=device))
@@ -173,6 +177,9 @@ class RecordColumns:
         c.cont_ap_base = self.ap_base.data_ptr() if self.ap_base is not None else None
         c.ap_delta = 1 if self.ap_delta else 0
         c.flags = _lib.WS_ALIAS_QS if getattr(self, "alias_qs", False) else 0
+        if getattr(self, "names", None) is not None:
+            c.names, c.name_off, c.name_len = self.names.data_ptr(), self.name_off.data_ptr(), self.name_len.data_ptr()
+        c.capture_names = 1 if getattr(self, "capture_names", False) else 0
         return c
 
 
@@ -231,10 +238,15 @@ class CramRecordReader:
         self.feats = FeatureBatch(device, n_reads, feature_cap)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
         self.bases_cap, self.seq_cap = int(bases_cap), max(int(seq_cap), 1)
+        # read names stay in the RN stream: offset (relative to the arena) and length per record, -1 = the record has none
+        self.name_off = torch.zeros(n_reads, dtype=torch.int64, device=device)
+        self.name_len = torch.full((n_reads,), -1, dtype=torch.int32, device=device)
 
-    def read(self, arena, series_off, series_len, cont_first, series_bytes, multiref=None, ap_base=None, ap_delta=True):
+    def read(self, arena, series_off, series_len, cont_first, series_bytes, multiref=None, ap_base=None, ap_delta=True,
+             capture_names=False):
         """arena / series_off / series_len / cont_first: device tensors (cont_first int32 [n_cont + 1]).  Stream-ordered."""
         torch = _torch()
+        self.cols.capture_names = bool(capture_names)
         self.cols.multiref = _dev(multiref, torch.uint8, self.device) if multiref is not None else None
         self.cols.ap_base = _dev(ap_base, torch.int32, self.device) if ap_base is not None else None
         self.cols.ap_delta = bool(ap_delta)
@@ -244,6 +256,7 @@ class CramRecordReader:
         o.bases, o.quals, o.bases_cap = self.bases.data_ptr(), self.quals.data_ptr(), self.bases_cap
         o.seq, o.seq_off, o.seq_cap = self.seq.data_ptr(), self.seq_off.data_ptr(), self.seq_cap
         o.rflags = self.rflags.data_ptr()
+        o.name_off, o.name_len = self.name_off.data_ptr(), self.name_len.data_ptr()
         self._keep = (cont_first, series_off, series_len)
         _lib.check(_lib.lib().cramgpu_read_series_dev(self.engine.handle, self.n, self.n_cont, cont_first.data_ptr(),
                                                       arena if isinstance(arena, int) else arena.data_ptr(),

@@ -315,8 +315,11 @@ int32_t cramgpu_restore_quals_dev(cramgpu_ctx* ctx, int32_t n_reads, const int32
  * order is spelled out in source by the reference's own readers,
  * src/main/java/htsjdk/samtools/cram/encoding/reader/ReaderToBAM.java:64-176 and ReadFeatureBuffer.java:41-100.
  * A series is addressed by its content id = htsjdk EncodingKey ordinal.  Integer series are ITF8, FC / BS / BA / QS are
- * bytes, IN / SC are byte arrays closed by '\t' (ByteArrayStopEncoding).  Read names and tag values (RN, TN, TC and
- * the per-tag series) are strings the host keeps: their slots stay empty.
+ * bytes, IN / SC / RN are byte arrays closed by '\t' (ByteArrayStopEncoding).  Read names (RN) travel when the caller
+ * hands over the name bytes (cramgpu_record_cols.names): for every record when capture_names is set
+ * (CompressionHeader.readNamesIncluded), otherwise for the detached records only — Writer#write's two RN lines, mirrored
+ * in source by ReaderToBAM.java:86-93.  Tag values (TN, TC and the per-tag series, a series set that depends on the
+ * file's tag dictionary) are the host's: their slots stay empty.
  * ===================================================================================================== */
 #define CRAMGPU_N_SERIES 30
 enum {
@@ -358,6 +361,11 @@ typedef struct {
                                      first record's own start (delta 0) */
     int32_t ap_delta;             /* CompressionHeader.AP_seriesDelta */
     int32_t flags;                /* writer options: CRAMGPU_WS_* */
+    const uint8_t* names;         /* writer: bytes the read names lie in (e.g. the BAM stripe), or NULL = RN stays empty */
+    const int64_t* name_off;      /*   [n_reads] offset of record r's name in names */
+    const int32_t* name_len;      /*   [n_reads] its length (no terminator; the stream gets the '\t') */
+    int32_t capture_names;        /* CompressionHeader.readNamesIncluded: every record carries its name (writer and reader) */
+    int32_t reserved;
 } cramgpu_record_cols;
 
 /* Writer#write for every record of every container of the batch.  Needs reads->bases, quals, base_off, read_len,
@@ -386,6 +394,9 @@ typedef struct {
     int64_t seq_cap;
     uint8_t* rflags;     /* [n_reads] or NULL: CRAMGPU_RF_UNMAPPED / UNKNOWN_BASES / FORCE_QS from BF / CF, the per-read flags
                             cramgpu_restore_bases_dev and cramgpu_restore_quals_dev take */
+    int64_t* name_off;   /* [n_reads] or NULL: where record r's name lies in the RN stream, relative to d_arena (the names stay
+                            where they are, as cramgpu_bam_decode_dev leaves them in the stripe) */
+    int32_t* name_len;   /* [n_reads] or NULL: its length, -1 for a record that carries no name */
 } cramgpu_read_out;
 
 /* CramRecordReader#read for every record of every container of the batch: the inverse of cramgpu_write_series_dev.

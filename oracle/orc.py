@@ -385,9 +385,14 @@ def itf8(values):
 
 
 def write_series(cols, read_len, aln_start, mapq, bases, quals, base_off, feats, multiref=False, ap_base=None, ap_delta=True,
-                 lo=0, hi=None):
+                 lo=0, hi=None, names=None, capture_names=False):
     """Writer#write over records [lo, hi) of a batch (one slice): cols = dict of the RECORD_COLS int32 arrays, feats = dict
-    off/op/pos/a/b.  Returns the N_SERIES byte strings (index = content id)."""
+    off/op/pos/a/b.  Returns the N_SERIES byte strings (index = content id).
+    names (a list of bytes, one per record of the batch): the RN series.  A series is a stream of its own, so the two RN
+    lines of Writer#write — `if (captureReadNames) readNameC.writeData(name)` in front of the mate block and
+    `if (!captureReadNames) readNameC.writeData(name)` inside `if (r.isDetached())`, the order the reference's own reader
+    spells out at src/main/java/htsjdk/samtools/cram/encoding/reader/ReaderToBAM.java:86-93 — are restated here: the name and
+    the stop byte '\t' (ByteArrayStopEncoding) of every record that carries one, in record order."""
     hi = len(read_len) if hi is None else hi
     n = hi - lo
     i32 = lambda a: np.ascontiguousarray(np.asarray(a)[lo:hi], np.int32)
@@ -411,7 +416,31 @@ def write_series(cols, read_len, aln_start, mapq, bases, quals, base_off, feats,
                                _p(out), ctypes.c_int64(cap), _p(out_len))
     if r != 0:
         raise RuntimeError("oracle write_series error %d" % r)
-    return [out[k * cap:k * cap + int(out_len[k])].tobytes() for k in range(N_SERIES)]
+    res = [out[k * cap:k * cap + int(out_len[k])].tobytes() for k in range(N_SERIES)]
+    if names is not None:
+        cf = np.asarray(cols["comp_flags"])[lo:hi]
+        res[SERIES_ID["RN"]] = b"".join(bytes(names[lo + i]) + b"\t" for i in range(n) if capture_names or (int(cf[i]) & 2))
+    return res
+
+
+def read_names(streams, comp_flags, capture_names=False):
+    """The read names CramRecordReader#read hands out (ReaderToBAM.java:86-93): the items of the RN stream, closed by '\t',
+    go to every record (names captured) or to the detached records in order; None for a record that carries none.  A slice
+    written without names has an empty RN stream."""
+    rn = streams[SERIES_ID["RN"]]
+    if not rn and not capture_names:
+        return [None] * len(comp_flags)
+    assert rn.endswith(b"\t") or not rn
+    items = rn.split(b"\t")[:-1]
+    out, k = [], 0
+    for cf in comp_flags:
+        if capture_names or (int(cf) & 2):
+            out.append(items[k])
+            k += 1
+        else:
+            out.append(None)
+    assert k == len(items), "surplus read names"
+    return out
 
 
 def read_series(streams, n_reads, multiref=False, ap_base=0, ap_delta=True):

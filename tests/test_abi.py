@@ -34,10 +34,10 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.HostReadResults) == 48 + 5 * 8
     assert ctypes.sizeof(_lib.HostRecords) == 16 + 7 * 8 + 48 + 3 * 8 + 8
     assert ctypes.sizeof(_lib.HostRestoreResults) == 32
-    assert ctypes.sizeof(_lib.RecordCols) == 12 * 8 + 8
+    assert ctypes.sizeof(_lib.RecordCols) == 12 * 8 + 8 + 3 * 8 + 8
     assert ctypes.sizeof(_lib.BamCols) == 22 * 8
     assert ctypes.sizeof(_lib.BamOut) == 22 * 8
-    assert ctypes.sizeof(_lib.ReadOut) == 11 * 8
+    assert ctypes.sizeof(_lib.ReadOut) == 13 * 8
 
 
 def test_host_only_entry_points():

@@ -176,6 +176,9 @@ def test_series_writer_test_bodies(hostsim, orc, monkeypatch):
     t.test_writer_feeds_the_encoder(orc)
     t.test_reader_matches_oracle_and_inverts_writer(orc, 0, [1])
     t.test_reader_matches_oracle_and_inverts_writer(orc, 2, [300, 5, 257])
+    t.test_read_names_series(orc, 0, [1], True)
+    t.test_read_names_series(orc, 1, [300, 7], False)
+    t.test_read_names_series(orc, 2, [260, 5, 257], True)
 
 
 def test_bam_test_bodies(hostsim, orc, monkeypatch):

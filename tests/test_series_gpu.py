@@ -236,3 +236,72 @@ def test_reader_matches_oracle_and_inverts_writer(orc, seed, sizes):
                 small.check()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed,sizes,capture", [(0, [1], True), (1, [300, 7], False), (2, [700, 5, 256, 257], True), (3, [64, 1, 1000], False)])
+def test_read_names_series(orc, seed, sizes, capture):
+    """RN: the writer puts a record's name + '\\t' for every record (names captured) or for the detached ones (Writer#write;
+    ReaderToBAM.java:86-93), the reader hands every record the place of its name in the stream; both against the oracle.
+    Names of 0 to 40 bytes lie in an arena of their own in shuffled order (offsets, as a BAM stripe gives them)."""
+    import torch
+    from cramtools_amd import external_compression as xc, records
+    rng = np.random.default_rng(300 + seed)
+    reads, cols, feats, parts = _batch(rng, sizes)
+    n_cont, n = len(sizes), reads.n
+    names = [bytes(rng.integers(33, 127, int(rng.integers(0, 41)), dtype=np.uint8)) for _ in range(n)]
+    order = rng.permutation(n)
+    name_off, at = np.zeros(n, np.int64), 3
+    blob = bytearray(b"xyz")
+    for r in order:
+        name_off[r] = at
+        blob += names[r] + b"#"
+        at += len(names[r]) + 1
+    name_len = np.array([len(x) for x in names], np.int32)
+    d_names = torch.as_tensor(np.frombuffer(bytes(blob) + bytes(16), np.uint8).copy()).to(DEV)
+    d_noff, d_nlen = torch.as_tensor(name_off).to(DEV), torch.as_tensor(name_len).to(DEV)
+    eng = xc.Engine(0)
+    try:
+        rc = records.RecordColumns(DEV, n, names=d_names, name_off=d_noff, name_len=d_nlen, capture_names=capture, **cols)
+        w = records.Writer(eng, DEV, n_cont, 8 * int(reads.bases.numel()) + 120 * n + 4096)
+        w.write(reads, rc, feats)
+        off, ln = w.lengths()
+        arena = w.arena.cpu().numpy()
+        r0 = 0
+        all_names = []
+        for c, p in enumerate(parts):
+            want = orc.write_series(p["cols"], p["read_len"], p["aln_start"], p["mapq"], p["bases"], p["quals"], p["base_off"],
+                                    p["feats"], names=names[r0:r0 + p["n"]], capture_names=capture)
+            for k in range(30):
+                got = arena[int(off[c, k]):int(off[c, k]) + int(ln[c, k])].tobytes()
+                assert got == want[k], (c, k, len(got), len(want[k]))
+            all_names += orc.read_names(want, p["cols"]["comp_flags"], capture)
+            r0 += p["n"]
+        cont_first = torch.as_tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)).to(DEV)
+        rd = records.CramRecordReader(eng, DEV, n, n_cont, int(reads.bases.numel()), feats.count + 8, int(reads.bases.numel()))
+        rd.read(w.arena, w.off, w.len, cont_first, int(w.arena.numel()), capture_names=capture)
+        rd.check()
+        g_off, g_len = rd.name_off.cpu().numpy(), rd.name_len.cpu().numpy()
+        for r in range(n):
+            if all_names[r] is None:
+                assert g_len[r] == -1, r
+            else:
+                assert arena[int(g_off[r]):int(g_off[r]) + int(g_len[r])].tobytes() == all_names[r] == names[r], r
+        # a container written WITHOUT names reads back with no names and no complaint
+        rc2 = records.RecordColumns(DEV, n, **cols)
+        w.write(reads, rc2, feats)
+        w.lengths()
+        rd.read(w.arena, w.off, w.len, cont_first, int(w.arena.numel()))
+        rd.check()
+        assert bool((rd.name_len == -1).all().item())
+        # one name short: the reader notices
+        rc3 = records.RecordColumns(DEV, n, names=d_names, name_off=d_noff, name_len=d_nlen, capture_names=True, **cols)
+        w.write(reads, rc3, feats)
+        w.lengths()
+        last = int(ln.shape[0]) - 1
+        cut = len(names[n - 1]) + 1
+        w.len[last * 30 + 12] -= cut
+        rd.read(w.arena, w.off, w.len, cont_first, int(w.arena.numel()), capture_names=True)
+        with pytest.raises(RuntimeError):
+            rd.check()
+    finally:
+        eng.close()
