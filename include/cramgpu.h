@@ -417,7 +417,7 @@ int32_t cramgpu_read_series_dev(cramgpu_ctx* ctx, int32_t n_reads, int32_t n_con
  * Container assembly and BAM records: what stands between the reader's columns and the
  * BAM stripe of src/main/java/htsjdk/samtools/cram/paralell/CramToBam_OBA_Function.java:64-75 (normalize, then per record
  * Cram2SamRecordFactory#create + BAMRecordCodec#encode), and between the BAM stripe of Bam_OBA_Supplier.java:45-82 and
- * the columns K3 takes.  BGZF (de)compression stays with the host.
+ * the columns K3 takes.  The BGZF members either side are cramgpu_gunzip_dev / cramgpu_gzip_dev (below).
  * ===================================================================================================== */
 
 /* CIGAR of every mapped record from its read features — htsjdk!build/Cram2SamRecordFactory#getCigar2 (L119-225); the

@@ -184,3 +184,27 @@ def mate_batch(rng, sizes):
     return dict(n=len(names), cont_first=np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), cols=cols,
                 aln_start=np.asarray(start, np.int32), aln_end=np.asarray(end, np.int32),
                 names=np.frombuffer(b"".join(names) + b"\0", np.uint8), name_off=name_off, kind=want_kind)
+
+
+# ---- the reference's own BAM-record test inputs ----
+# src/test/java/net/sf/cram/TestBAMRecordView.java:47-66 builds ONE record through BAMRecordView: refID 0, start 77,
+# mapping score 44, index bin 99, flags 555, mate 0 / 78, insert size 133, "name1", 10M, ten 'A', ten 'B' (raw bytes: the
+# test passes "BBBBBBBBBB".getBytes()), tag AM:A:Q.  The test prints the bytes and compares nothing; the bytes below are
+# worked from src/main/java/htsjdk/samtools/cram/encoding/reader/BAMRecordView.java (the layout py_bam_record states on its
+# own).  The bin 99 is a value the test sets by hand; an encoder computes reg2bin of the alignment (BAMRecordCodec#encode).
+REF_VIEW_RECORD = dict(ref_id=0, start=77, end=86, mapq=44, bin_set_by_the_test=99, flags=555, mate_ref=0, mate_start=78, tlen=133,
+                       name="name1", cigar=[(10 << 4) | 0], seq="A" * 10, qual=b"B" * 10, tags=b"AMAQ")
+# src/test/java/htsjdk/samtools/cram/encoding/reader/BAMRecordViewTest.java:78-124 writes an unmapped record twice
+# ("readName", then "2") through its translate() (:35-49, which never sets the index bin: it stays 0) and reads both back
+# with BAMRecordCodec: flags 4, no reference, start 0, mapping quality 0, empty CIGAR, no mate, base "A", score '!' = 0.
+REF_UNMAPPED_PAIR = [dict(name="readName"), dict(name="2")]
+
+
+def ref_view_record_bytes(bin_):
+    r = REF_VIEW_RECORD
+    return py_bam_record(r["ref_id"], r["start"], r["mapq"], bin_, r["flags"], r["name"], r["cigar"], r["seq"], r["qual"],
+                         r["mate_ref"], r["mate_start"], r["tlen"], r["tags"])
+
+
+def ref_unmapped_pair_bytes():
+    return b"".join(py_bam_record(-1, 0, 0, 0, 4, r["name"], [], "A", b"\0", -1, 0, 0) for r in REF_UNMAPPED_PAIR)

@@ -303,3 +303,49 @@ def test_content_digests_match_oracle(orc, seed, sizes, max_len):
         assert tags[5][1] == hashlib.sha1(b"").digest()
     finally:
         eng.close()
+
+
+def test_reference_bam_record_test_inputs():
+    """The records the reference's own tests build (TestBAMRecordView.java:47-66, BAMRecordViewTest.java:78-124) through the
+    device codec; expected bytes from the independent statement of BAMRecordView's layout in tests/bam_cases.py."""
+    import torch
+    from cramtools_amd import bam, external_compression as xc, records
+    eng = xc.Engine(0)
+    try:
+        codec = bam.BAMRecordCodec(eng, DEV)
+        r = bc.REF_VIEW_RECORD
+        i32 = lambda *v: np.array(v, np.int32)
+        cols = records.RecordColumns(DEV, 1, bam_flags=i32(555 & ~0x28), ref_id=i32(0), mate_flags=i32(3), mate_ref=i32(0),
+                                     mate_start=i32(78), tlen=i32(133))
+        pad = lambda b: _t(np.frombuffer(b + bytes(16), np.uint8))
+        want = bc.ref_view_record_bytes(bc.reg2bin(76, 86))
+        g_bam, g_off, g_st = codec.encode(cols, _t(i32(10)), _t(i32(77)), _t(i32(86)), _t(np.array([44], np.uint8)),
+                                          _t(np.array([0, 10], np.int64)), pad(r["seq"].encode()), pad(r["qual"]), _t(i32(1)),
+                                          _t(np.array([0, 1], np.int64)), _t(np.array(r["cigar"], np.int32)), len(want),
+                                          names=pad(b"name1"), name_off=_t(np.array([0, 5], np.int64)), tags=pad(r["tags"]),
+                                          tag_off=_t(np.array([0, 4], np.int64)))
+        assert g_bam[:len(want)].cpu().numpy().tobytes() == want and int(g_st[0].item()) == 0 and g_off.tolist() == [0, len(want)]
+        raw = bc.ref_view_record_bytes(99)  # as the reference's test leaves it: index bin 99, set by hand
+        d = codec.decode(pad(raw), _t(np.array([0, len(raw)], np.int64)), 10, 1)
+        one = lambda k: int(d[k][0].item())
+        assert (one("ref_id"), one("aln_start"), one("mapq"), one("bam_flags")) == (0, 77, 44, 555) and one("status") == 0
+        assert (one("mate_ref"), one("mate_start"), one("tlen"), one("read_len")) == (0, 78, 133, 10)
+        assert d["bases"][:10].cpu().numpy().tobytes() == b"A" * 10 and d["quals"][:10].cpu().numpy().tobytes() == b"B" * 10
+        assert raw[one("name_off"):one("name_off") + one("name_len")] == b"name1"
+        assert raw[one("tag_off"):one("tag_off") + one("tag_len")] == b"AMAQ"
+        # the unmapped record, twice ("readName", "2"), in one stripe
+        cols = records.RecordColumns(DEV, 2, bam_flags=i32(4, 4), ref_id=i32(-1, -1), mate_ref=i32(-1, -1))
+        want = bc.ref_unmapped_pair_bytes()
+        g_bam, g_off, g_st = codec.encode(cols, _t(i32(1, 1)), _t(i32(0, 0)), _t(i32(0, 0)), _t(np.zeros(2, np.uint8)),
+                                          _t(np.array([0, 1, 2], np.int64)), pad(b"AA"), pad(b"\0\0"), _t(i32(0, 0)),
+                                          _t(np.array([0, 0, 0], np.int64)), _t(np.zeros(1, np.int32)), len(want),
+                                          names=pad(b"readName2"), name_off=_t(np.array([0, 8, 9], np.int64)))
+        assert g_bam[:len(want)].cpu().numpy().tobytes() == want and not g_st.any().item()
+        rec_off = codec.index(np.frombuffer(want, np.uint8))
+        assert rec_off.tolist() == [0, 47, len(want)]
+        d = codec.decode(pad(want), _t(rec_off), 2, 0)
+        assert d["ref_id"].tolist() == [-1, -1] and d["bam_flags"].tolist() == [4, 4] and d["read_len"].tolist() == [1, 1]
+        assert d["status"].tolist() == [0, 0] and d["quals"][:2].tolist() == [0, 0]
+    finally:
+        eng.close()
+        torch.cuda.empty_cache()

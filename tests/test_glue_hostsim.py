@@ -193,6 +193,8 @@ def test_bam_test_bodies(hostsim, orc, monkeypatch):
     t.test_set_mate_info_matches_oracle(orc, 2, [700, 5, 256, 257])
     t.test_content_digests_match_oracle(orc, 0, [1, 0, 3], 60)
     t.test_content_digests_match_oracle(orc, 1, [700, 256], 300)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    t.test_reference_bam_record_test_inputs()
 
 
 def test_gunzip_test_bodies(hostsim, monkeypatch):

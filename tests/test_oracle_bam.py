@@ -230,3 +230,37 @@ def test_content_digests_known_answers(orc):
     assert out[0, 0] == (2 * 0xCBF43926) & 0xFFFFFFFF
     assert out[0, 1] == (zlib.crc32(b"!" * 9) + 0xCBF43926) & 0xFFFFFFFF
     assert out[1, 0] == zlib.crc32(b"ACGT") and out[2].tolist() == [0, 0]
+
+
+def test_reference_bam_record_test_inputs(orc):
+    """The records the reference's own tests build (TestBAMRecordView.java:47-66, BAMRecordViewTest.java:78-124), through the
+    oracle's encoder and decoder; expected bytes from an independent statement of BAMRecordView's layout (tests/bam_cases.py)."""
+    r = bc.REF_VIEW_RECORD
+    bases = np.frombuffer(r["seq"].encode(), np.uint8)
+    # flags 555 = paired | proper | mate unmapped (0x8) | mate reverse (0x20) | QC fail: the two mate bits travel as mate flags
+    got, rec_off, status, tot = orc.bam_encode([0], [77], [86], [44], [555 & ~0x28], [3], [0], [78], [133], [10], [0, 10], bases,
+                                               np.frombuffer(r["qual"], np.uint8), [1], [1], [0, 1], r["cigar"],
+                                               names=np.frombuffer(b"name1", np.uint8), name_off=[0, 5],
+                                               tags=np.frombuffer(r["tags"], np.uint8), tag_off=[0, 4])
+    want = bc.ref_view_record_bytes(bc.reg2bin(76, 86))
+    assert got == want and status[0] == 0 and tot == len(want) == 4 + 32 + 6 + 4 + 5 + 10 + 4
+    # the bytes as the reference's test makes them (bin 99) read back to the fields the test set
+    raw = bc.ref_view_record_bytes(99)
+    assert raw[14:16] == (99).to_bytes(2, "little")
+    d = orc.bam_decode(raw, orc.bam_index(raw))
+    assert (int(d["ref_id"][0]), int(d["aln_start"][0]), int(d["mapq"][0]), int(d["bam_flags"][0])) == (0, 77, 44, 555)
+    assert (int(d["mate_ref"][0]), int(d["mate_start"][0]), int(d["tlen"][0]), int(d["read_len"][0])) == (0, 78, 133, 10)
+    assert d["bases"][:10].tobytes() == b"A" * 10 and d["quals"][:10].tobytes() == b"B" * 10 and d["cigar"][0] == (10 << 4)
+    assert raw[int(d["name_off"][0]):int(d["name_off"][0]) + int(d["name_len"][0])] == b"name1"
+    assert raw[int(d["tag_off"][0]):int(d["tag_off"][0]) + int(d["tag_len"][0])] == b"AMAQ"
+    # the unmapped record, twice, in one stripe
+    names = b"readName2"
+    got, rec_off, status, tot = orc.bam_encode([-1, -1], [0, 0], [0, 0], [0, 0], [4, 4], [0, 0], [-1, -1], [0, 0], [0, 0], [1, 1],
+                                               [0, 1, 2], np.frombuffer(b"AA", np.uint8), np.zeros(2, np.uint8), [1, 1], [0, 0],
+                                               [0, 0, 0], np.zeros(1, np.uint32), names=np.frombuffer(names, np.uint8),
+                                               name_off=[0, 8, 9])
+    want = bc.ref_unmapped_pair_bytes()
+    assert got == want and not status.any() and rec_off.tolist() == [0, 4 + 32 + 9 + 1 + 1, len(want)]
+    d = orc.bam_decode(want, orc.bam_index(want))
+    assert d["ref_id"].tolist() == [-1, -1] and d["aln_start"].tolist() == [0, 0] and d["bam_flags"].tolist() == [4, 4]
+    assert d["read_len"].tolist() == [1, 1] and d["n_cigar"].tolist() == [0, 0] and d["quals"][:2].tolist() == [0, 0]
