@@ -161,6 +161,11 @@ SYMBOLS = {
     "cramgpu_ticket_wait": (I32, [P, I64]),
     "cramgpu_rans_coalesced": (I32, [P, I32, P, I64, P, I64, P, I32, P, P]),
     "cramgpu_coalesce_stats": (I32, [P, P, P, P]),
+    "cramgpu_pool_open": (P, [I32, I32]),
+    "cramgpu_pool_close": (None, [P]),
+    "cramgpu_pool_devices": (I32, [P]),
+    "cramgpu_pool_submit": (I32, [P, I64, I32, P, I64, P, I64, P, I32, P, P]),
+    "cramgpu_pool_next": (I32, [P, P]),
     "cramgpu_extract_features_dev": (I64, [P, P, P, P, P, P]),
     "cramgpu_substitution_matrix": (None, [P, P]),
     "cramgpu_assign_codes_dev": (I32, [P, I32, P, I32, P, P, P]),

@@ -740,7 +740,7 @@ int32_t cramgpu_rans_decode_batch(cramgpu_ctx* c, const uint8_t* in_arena, int64
 // ---- asynchronous level 1 ----
 void* cramgpu_host_alloc(int64_t bytes) {
     void* p = nullptr;
-    if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable) != hipSuccess) return nullptr;  // pinned for every GPU (device pool)
     return p;
 }
 void cramgpu_host_free(void* p) {
@@ -1332,6 +1332,92 @@ int32_t cramgpu_coalesce_stats(cramgpu_coalescer* q, int64_t* n_batches, int64_t
     if (n_submissions) *n_submissions = q->n_subs;
     if (largest_batch) *largest_batch = q->largest;
     return 0;
+}
+
+// ---- device pool: container k -> GPU k mod G, results in ordinal order (OrderingConveyer.java:24-38) ----
+}  // extern "C"
+
+struct cramgpu_pool {
+    std::vector<cramgpu_ctx*> ctx;
+    std::vector<cramgpu_coalescer*> queue;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::unordered_map<int64_t, int64_t> ticket;  // ordinal -> ticket of queue[ordinal mod G]
+    int64_t next = 0;
+    bool closing = false;
+};
+
+extern "C" {
+
+cramgpu_pool* cramgpu_pool_open(int32_t n_devices, int32_t max_batches) {
+    const int32_t have = cramgpu_device_count();
+    if (n_devices <= 0) n_devices = have;
+    if (have <= 0 || n_devices > have) {
+        fail(CRAMGPU_E_NO_DEVICE, "cramgpu_pool_open: fewer HIP devices than asked for (libcramgpu has no CPU path)");
+        return nullptr;
+    }
+    cramgpu_pool* p = new cramgpu_pool();
+    for (int32_t d = 0; d < n_devices; d++) {
+        cramgpu_ctx* c = cramgpu_open(d);
+        cramgpu_coalescer* q = c ? cramgpu_coalescer_open(c, max_batches) : nullptr;
+        if (!q) {
+            if (c) cramgpu_close(c);
+            cramgpu_pool_close(p);
+            return nullptr;
+        }
+        p->ctx.push_back(c);
+        p->queue.push_back(q);
+    }
+    return p;
+}
+
+void cramgpu_pool_close(cramgpu_pool* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->closing = true;
+    }
+    p->cv.notify_all();
+    for (auto* q : p->queue) cramgpu_coalescer_close(q);
+    for (auto* c : p->ctx) cramgpu_close(c);
+    delete p;
+}
+
+int32_t cramgpu_pool_devices(cramgpu_pool* p) { return p ? (int32_t)p->ctx.size() : 0; }
+
+int32_t cramgpu_pool_submit(cramgpu_pool* p, int64_t ordinal, int32_t decode, const uint8_t* in_arena, int64_t in_bytes,
+                            uint8_t* out_arena, int64_t out_bytes, const cramgpu_block* blocks, int32_t n, int32_t* out_len,
+                            int64_t* out_pos) {
+    if (!p || ordinal < 0) return fail(CRAMGPU_E_ARG, "pool_submit: bad argument");
+    const size_t g = (size_t)(ordinal % (int64_t)p->queue.size());
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (ordinal < p->next || p->ticket.count(ordinal)) return fail(CRAMGPU_E_ARG, "pool_submit: ordinal used twice");
+    }
+    const int64_t t = cramgpu_rans_enqueue(p->queue[g], decode, in_arena, in_bytes, out_arena, out_bytes, blocks, n, out_len, out_pos);
+    if (t < 0) return (int32_t)t;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->ticket[ordinal] = t;
+    }
+    p->cv.notify_all();
+    return 0;
+}
+
+int32_t cramgpu_pool_next(cramgpu_pool* p, int64_t* ordinal) {
+    if (!p || !ordinal) return fail(CRAMGPU_E_ARG, "pool_next: bad argument");
+    int64_t k, t;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        k = p->next;
+        p->cv.wait(lk, [&] { return p->closing || p->ticket.count(k) != 0; });
+        if (!p->ticket.count(k)) return fail(CRAMGPU_E_ARG, "pool_next: pool closed");
+        t = p->ticket[k];
+        p->ticket.erase(k);
+        p->next = k + 1;
+    }
+    *ordinal = k;
+    return cramgpu_ticket_wait(p->queue[(size_t)(k % (int64_t)p->queue.size())], t);
 }
 
 // ---- level 0 ----

@@ -80,6 +80,81 @@ class ContainerQueue:
         return self._out
 
 
+class DevicePool:
+    """All GPUs of the node behind one handle (cramgpu_pool_*): container `ordinal` goes to GPU `ordinal mod G` through
+    that GPU's coalescing queue, results come back in ordinal order (paralell/OrderingConveyer.java:24-38).  `submit` may be
+    called from any thread; `next()` from the writer."""
+
+    def __init__(self, n_devices=0, max_batches=0):
+        from . import _lib
+        self._p = _lib.lib().cramgpu_pool_open(n_devices, max_batches)
+        if not self._p:
+            raise _lib.CramGpuError(_lib.E_NO_DEVICE, _lib.last_error())
+        self._held = {}
+
+    @property
+    def devices(self):
+        from . import _lib
+        return int(_lib.lib().cramgpu_pool_devices(self._p))
+
+    def submit(self, ordinal, datas, orders):
+        """The external blocks of one container (orders=None: streams to decode)."""
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        from .external_compression import Engine
+        L = _lib.lib()
+        decode = orders is None
+        n = len(datas)
+        if decode:
+            raws = []
+            for s in datas:
+                b = np.frombuffer(bytes(s), np.uint8)
+                raws.append(0 if b.size == 0 else _lib.check(L.cramgpu_rans_raw_size(b.ctypes.data, b.size)))
+            blocks, in_bytes, out_bytes = Engine.plan_decode([len(s) for s in datas], raws)
+        else:
+            blocks, in_bytes, out_bytes = Engine.plan_encode([len(d) for d in datas], orders)
+        h_in, h_out, h_len = L.cramgpu_host_alloc(in_bytes), L.cramgpu_host_alloc(max(out_bytes, 16)), L.cramgpu_host_alloc(4 * max(n, 1))
+        if not (h_in and h_out and h_len):
+            raise _lib.CramGpuError(_lib.E_HIP, "cramgpu_host_alloc failed")
+        arena = np.ctypeslib.as_array(C.cast(h_in, C.POINTER(C.c_uint8)), shape=(in_bytes,))
+        arena[:] = 0
+        for i, d in enumerate(datas):
+            arena[blocks[i].in_off:blocks[i].in_off + len(d)] = np.frombuffer(bytes(d), np.uint8)
+        self._held[ordinal] = (blocks, n, out_bytes, h_in, h_out, h_len)
+        _lib.check(L.cramgpu_pool_submit(self._p, ordinal, 1 if decode else 0, h_in, in_bytes, h_out, out_bytes, C.addressof(blocks), n,
+                                         h_len, None))
+
+    def next(self):
+        """-> (ordinal, [bytes]) of the next container in ordinal order; blocks until it is done."""
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        L = _lib.lib()
+        k = C.c_int64(-1)
+        rc = L.cramgpu_pool_next(self._p, C.byref(k))
+        blocks, n, out_bytes, h_in, h_out, h_len = self._held.pop(k.value)
+        try:
+            _lib.check(rc)
+            out = np.ctypeslib.as_array(C.cast(h_out, C.POINTER(C.c_uint8)), shape=(max(out_bytes, 16),))
+            lens = np.ctypeslib.as_array(C.cast(h_len, C.POINTER(C.c_int32)), shape=(max(n, 1),))
+            res = []
+            for i in range(n):
+                if lens[i] < 0:
+                    raise _lib.CramGpuError(int(lens[i]), "container %d block %d" % (k.value, i))
+                res.append(out[blocks[i].out_off:blocks[i].out_off + lens[i]].tobytes())
+            return k.value, res
+        finally:
+            for p in (h_in, h_out, h_len):
+                L.cramgpu_host_free(p)
+
+    def close(self):
+        from . import _lib
+        if self._p:
+            _lib.lib().cramgpu_pool_close(self._p)
+            self._p = None
+
+
 class EngineCoder:
     """`.run(job)` adapter of one `external_compression.Engine` (= one GPU) for `ContainerQueue`: a job is the external
     blocks of one container, `(datas, orders)` to encode or `(streams, None)` to decode, as

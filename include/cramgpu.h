@@ -199,6 +199,23 @@ int32_t cramgpu_rans_coalesced(cramgpu_coalescer* q, int32_t decode, const uint8
 /* launches made, submissions served and the most submissions one launch held, since the queue was opened */
 int32_t cramgpu_coalesce_stats(cramgpu_coalescer* q, int64_t* n_batches, int64_t* n_submissions, int64_t* largest_batch);
 
+/* Device pool: all GPUs of the node behind one handle, for a host that is ONE process (a JVM) — SURVEY.md §8(e).
+ * Containers are independent, so there is no collective: the container with ordinal k goes to GPU k mod G (one context and
+ * one coalescing queue per GPU) and results are handed back in ordinal order, which is what the reference's
+ * src/main/java/htsjdk/samtools/cram/paralell/OrderingConveyer.java:24-38 does with the OrderedByteArrays its worker
+ * threads return.  cramgpu_pool_submit may be called from any thread, in any order of ordinals (each ordinal once, counting
+ * from 0); arguments are those of cramgpu_rans_enqueue and the arenas should be pinned (cramgpu_host_alloc memory is
+ * pinned for every GPU).  cramgpu_pool_next blocks until the container with the NEXT ordinal (0, 1, 2, ...) is done, stores
+ * that ordinal and returns its code; called from one thread (the writer).  n_devices = 0: every visible GPU. */
+typedef struct cramgpu_pool cramgpu_pool;
+cramgpu_pool* cramgpu_pool_open(int32_t n_devices, int32_t max_batches);
+void cramgpu_pool_close(cramgpu_pool* p);
+int32_t cramgpu_pool_devices(cramgpu_pool* p);
+int32_t cramgpu_pool_submit(cramgpu_pool* p, int64_t ordinal, int32_t decode, const uint8_t* in_arena, int64_t in_bytes,
+                            uint8_t* out_arena, int64_t out_bytes, const cramgpu_block* blocks, int32_t n_blocks,
+                            int32_t* out_len, int64_t* out_pos);
+int32_t cramgpu_pool_next(cramgpu_pool* p, int64_t* ordinal);
+
 /* =====================================================================================================
  * Level 2 — record kernels over one container in flat (structure-of-arrays) form.
  * ===================================================================================================== */

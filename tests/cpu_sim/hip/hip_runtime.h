@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -70,8 +71,15 @@ inline uint64_t exchange(uint64_t v, int src) {
     pthread_barrier_wait(&w.bar);
     return r;
 }
+// One launch at a time, whatever host thread it comes from: blockDim / gridDim and the kernels' static "LDS" are global
+// here (the device pool and the coalescing queues launch from one dispatcher thread per device).
+inline std::mutex& launch_mutex() {
+    static std::mutex m;
+    return m;
+}
 template <class F>
 void launch(dim3 grid, dim3 block, size_t lds, F f) {
+    std::lock_guard<std::mutex> serial(launch_mutex());
     blockDim = block;
     gridDim = grid;
     const int nt = (int)block.x;
@@ -205,12 +213,16 @@ typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocPortable = 1 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 struct hipDeviceProp_t { int multiProcessorCount; };
 inline const char* hipGetErrorString(hipError_t) { return "sim"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) {  // HIPSIM_DEVICES: the device pool's routing is tested over several "devices"
+    const char* e = getenv("HIPSIM_DEVICES");
+    *n = e && atoi(e) > 0 ? atoi(e) : 1;
+    return hipSuccess;
+}
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 1; return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorUnknown; }

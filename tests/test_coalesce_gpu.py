@@ -125,3 +125,44 @@ def test_bad_submissions_and_capacity(engine, xc, orc):
         q.unrans([bytes(stream)])
     assert q.unrans([orc.rans(data, 1)]) == [data]
     q.close()
+
+
+def test_device_pool_orders_results(orc):
+    """cramgpu_pool_*: containers submitted out of order from several threads come back in ordinal order, each coded by the
+    GPU `ordinal mod G` (G = every visible GPU: one on a test box; tests/test_glue_hostsim.py runs it over three simulated
+    devices)."""
+    from cramtools_amd import sharding
+    rng = np.random.default_rng(13)
+    conts = [container(rng, k) for k in range(N_WINDOW)]
+    pool = sharding.DevicePool()
+    try:
+        assert pool.devices >= 1
+        order = rng.permutation(len(conts))
+        lock = threading.Lock()
+
+        def worker(share):
+            for k in share:
+                with lock:  # DevicePool.submit keeps a Python dict; the C call below it is thread-safe on its own
+                    pool.submit(int(k), *conts[k])
+
+        ths = [threading.Thread(target=worker, args=(order[t::3],)) for t in range(3)]
+        for t in ths:
+            t.start()
+        got = [pool.next() for _ in conts]  # waits for ordinal 0, 1, 2, ... while the workers are still submitting
+        for t in ths:
+            t.join()
+        assert [k for k, _ in got] == list(range(len(conts)))
+        for k, streams in got:
+            assert streams == [orc.rans(d, o) for d, o in zip(*conts[k])], k
+        # decode through the pool, and an ordinal used twice is refused
+        back = min(6, len(conts))
+        for k, streams in got[:back]:
+            pool.submit(len(conts) + k, streams, None)
+        for k in range(back):
+            kk, raws = pool.next()
+            assert kk == len(conts) + k and raws == conts[k][0]
+        from cramtools_amd import _lib
+        with pytest.raises(_lib.CramGpuError):
+            pool.submit(3, *conts[3])
+    finally:
+        pool.close()

@@ -95,6 +95,12 @@ def test_coalescer_test_bodies(hostsim, orc, monkeypatch):
         t.test_bad_submissions_and_capacity(eng, xc, orc)
     finally:
         eng.close()
+    monkeypatch.setenv("HIPSIM_DEVICES", "3")  # the pool's routing and ordering over three "devices"
+    from cramtools_amd import sharding
+    p = sharding.DevicePool()
+    assert p.devices == 3
+    p.close()
+    t.test_device_pool_orders_results(orc)
 
 
 def test_records_gpu_test_bodies(hostsim, katrec, orc, monkeypatch):
