@@ -1695,7 +1695,7 @@ int32_t cramgpu_gzip_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, co
     HIPCHK(hipSetDevice(c->device));
     if (n == 0) return 0;
     hipStream_t s = pick(c, stream);
-    const int waves = std::min(n, c->n_cu * std::max(1, std::min(env_int("CRAMGPU_GZIP_WAVES_PER_CU", 12), 32)));
+    const int waves = std::min(n, c->n_cu * std::max(1, std::min(env_int("CRAMGPU_GZIP_WAVES_PER_CU", 20), 32)));
     if (gzip_ws_bytes(waves) > c->d_gz_ws.cap) {
         if (c->gz_valid) HIPCHK(hipEventSynchronize(c->gz_use));  // the buffer about to be replaced may still be in use
         HIPCHK(c->d_gz_ws.reserve(gzip_ws_bytes(waves)));

@@ -552,19 +552,32 @@ constexpr int kNear = 8;  // at most 8: the near candidates come out of a 16-byt
 constexpr int kStageWords = 104;  // 31 carried bits + 64 tokens of at most 48 bits = 3103 bits = 97 words, + the spill words
 
 struct WaveLds {
-    uint16_t hash[kWHash];  // position + 1 of the latest occurrence in the block, 0 = none; the counting sort's 256 counters later
-    uint32_t cnt[kAll];     // symbol counts of the block (LDS atomics)
+    // Phases reuse each other's space (LDS per wave decides how many waves a CU holds, and the kernel lives on waves in
+    // flight: 52 / 38 / 30 ms for 20 000 BGZF blocks at 8 / 12 / 16 waves per CU):
+    //   hash: A — position + 1 of the latest occurrence in the block, 0 = none; B — the counting sort's 256 counters;
+    //         C — the staging words of the bit writer (kStageWords of them)
+    //   cnt:  A — symbol counts (LDS atomics), copied to freq in front of B;  work / syms: B — the code builder's arrays,
+    //         syms keeps the header's run-length tokens until they are written
+    union {
+        uint16_t hash[kWHash];
+        uint32_t stage[kStageWords];
+    };
+    union {
+        uint32_t cnt[kAll];
+        struct {
+            uint16_t work[kNL];
+            uint16_t syms[kAll];
+        };
+    };
     uint16_t freq[kAll];    // the counts as build_lengths wants them, then the (bit-reversed) codes
-    uint16_t work[kNL];
-    uint16_t syms[kAll];
     uint8_t len[kAll];
     uint16_t clfreq[kNC];
     uint8_t cllen[kNC];
     uint16_t num[16];
-    uint32_t stage[kStageWords];
     uint32_t crc[256];
     int32_t misc[8];  // hlit, hdist, hclen, nt, header bits
 };
+static_assert(sizeof(uint16_t) * kWHash >= sizeof(uint32_t) * kStageWords, "the staging words fit the match table");
 static_assert(kWHash >= 256, "the match table doubles as the 256 counters of the counting sort");
 
 #ifdef HIP_SIM
@@ -814,7 +827,7 @@ __device__ void wave_block(const uint8_t* p, int32_t n, bool last, WaveLds& S, u
     }
     __syncthreads();
     uint32_t body = 0;
-    for (int s = lane; s < kAll; s += 64) body += S.cnt[s] * (uint32_t)(S.len[s] + extra_bits_of(s));
+    for (int s = lane; s < kAll; s += 64) body += (uint32_t)S.freq[s] * (uint32_t)(S.len[s] + extra_bits_of(s));  // freq: still the counts
     for (int d = 32; d > 0; d >>= 1) body += (uint32_t)__shfl_xor((int)body, d);
     const int hlit = S.misc[0], hdist = S.misc[1], hclen = S.misc[2], nt = S.misc[3];
     const uint32_t hdr = (uint32_t)S.misc[4];
@@ -896,7 +909,10 @@ __device__ void wave_block(const uint8_t* p, int32_t n, bool last, WaveLds& S, u
     put(w, S.freq[256], S.len[256], l0);
 }
 
-__global__ __launch_bounds__(64) void gzip_wave_kernel(const uint8_t* in, uint8_t* out, const cramgpu_block* desc, int32_t n,
+#ifndef GZ_WPE
+#define GZ_WPE 5  // 96 VGPRs (20 bytes of spill), five waves per SIMD: 30.2 ms at 16 waves per CU, 27.2 at 20 (six: 27.0 at 21)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GZ_WPE, GZ_WPE))) void gzip_wave_kernel(const uint8_t* in, uint8_t* out, const cramgpu_block* desc, int32_t n,
                                                        int32_t* out_len, int32_t bgzf, uint32_t* ws) {
     __shared__ WaveLds S;
     const int lane = (int)threadIdx.x;
