@@ -676,10 +676,36 @@ __device__ void wave_block(const uint8_t* p, int32_t n, bool last, WaveLds& S, u
     __syncthreads();
     // ---- A: matches and tokens ----
     int32_t ntok = 0, carry = 0;
+    // the 16 input bytes around a lane's position (eight before it, eight at it), loaded a chunk AHEAD of their use: the
+    // kernel waits on memory 60 % of its wave cycles (SQ counters), and these loads depend on nothing
+    struct Win {
+        uint32_t w4, whi;
+        unsigned long long prev8;
+    };
+    auto load_win = [&](int32_t i) -> Win {
+        Win q{0u, 0u, 0ull};
+        if (i + 4 <= n)
+            q.w4 = ld32(p + i);
+        else if (i < n)
+            q.w4 = (uint32_t)p[i];
+        if (i + 8 <= n) q.whi = ld32(p + i + 4);
+        if (i + 4 <= n) {
+            if (i >= 8) {
+                q.prev8 = (unsigned long long)ld32(p + i - 8) | (unsigned long long)ld32(p + i - 4) << 32;
+            } else {
+                for (int k = 0; k < i; k++) q.prev8 |= (unsigned long long)p[k] << (8 * (8 - i + k));
+            }
+        }
+        return q;
+    };
+    Win nxt = load_win(lane);
     for (int32_t base = 0; base < n; base += 64) {
         const int32_t i = base + lane;
         const bool valid = i < n, can = i + 4 <= n;
-        const uint32_t w4 = can ? ld32(p + i) : (valid ? (uint32_t)p[i] : 0u);
+        (void)valid;
+        const Win cur = nxt;
+        if (base + 64 < n) nxt = load_win(i + 64);
+        const uint32_t w4 = cur.w4;
         const int lit = (int)(w4 & 255u);
         const uint32_t h = ((w4 & 0xFFFFFFu) * 2654435761u) >> (32 - kWHashBits);
         const int32_t cand = can ? (int32_t)S.hash[h] : 0;
@@ -702,7 +728,7 @@ __device__ void wave_block(const uint8_t* p, int32_t n, bool last, WaveLds& S, u
         const int32_t maxl = n - i < 258 ? n - i : 258;
         if (can) {
             const bool can8 = i + 8 <= n;
-            const unsigned long long w8 = can8 ? (unsigned long long)w4 | (unsigned long long)ld32(p + i + 4) << 32 : 0ull;
+            const unsigned long long w8 = can8 ? (unsigned long long)w4 | (unsigned long long)cur.whi << 32 : 0ull;
             auto measure = [&](unsigned long long c8, int d) {  // c8: the eight bytes at i - d
                 int l;
                 if (can8) {
@@ -714,12 +740,7 @@ __device__ void wave_block(const uint8_t* p, int32_t n, bool last, WaveLds& S, u
                 if (l >= 3 && l > mlen) mlen = l, dist = d;
             };
             // the eight bytes before the position and the eight at it are a 16-byte window that holds every near candidate
-            unsigned long long prev8 = 0;
-            if (i >= 8) {
-                prev8 = (unsigned long long)ld32(p + i - 8) | (unsigned long long)ld32(p + i - 4) << 32;
-            } else {
-                for (int k = 0; k < i; k++) prev8 |= (unsigned long long)p[k] << (8 * (8 - i + k));
-            }
+            const unsigned long long prev8 = cur.prev8;
             const unsigned long long cur8 = can8 ? w8 : (unsigned long long)w4;
 #pragma unroll
             for (int d = 1; d <= kNear; d++)
