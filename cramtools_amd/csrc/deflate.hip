@@ -82,6 +82,8 @@ __device__ __forceinline__ void flush_bytes(BitW& w, bool store = true) {  // to
     }
 }
 
+__device__ void lengths_from_sorted(int m, int max_len, Col8 len, Col16 A, Col16 S, Col16 num, bool assign);
+
 // Code lengths (<= max_len) of the symbols with a non-zero count; returns how many there are.  cnt: 256 cells of scratch
 // for the counting sort of large alphabets (none: insertion sort only).
 __device__ int build_lengths(Col16 freq, int n, int max_len, Col8 len, Col16 A, Col16 S, Col16 num, Col16 cnt) {
@@ -134,7 +136,19 @@ __device__ int build_lengths(Col16 freq, int n, int max_len, Col8 len, Col16 A, 
             S[j] = sym;
         }
     }
-    if (m == 1) len[S[0]] = 1;
+    lengths_from_sorted(m, max_len, len, A, S, num, true);
+    return m;
+}
+
+// (A, S) = (count, symbol) of the m used symbols, ascending by count: the length-limited code lengths.  assign == false
+// leaves the last step — lengths to symbols, from num[] and the sorted order — to the caller (the wave kernel spreads it
+// over its lanes).
+__device__ void lengths_from_sorted(int m, int max_len, Col8 len, Col16 A, Col16 S, Col16 num, bool assign) {
+    if (m == 1) {
+        for (int l = 0; l < 16; l++) num[l] = 0;
+        num[1] = 1;
+        if (assign) len[S[0]] = 1;
+    }
     if (m >= 2) {
         // Moffat & Katajainen, "In-place calculation of minimum-redundancy codes" (1995): A holds counts, then parent
         // indices of the internal nodes, then depths
@@ -192,11 +206,12 @@ __device__ int build_lengths(Col16 freq, int n, int max_len, Col8 len, Col16 A, 
             }
             total--;
         }
-        int k = 0;  // sorted order: rarest first, so the longest codes go first
-        for (int l = max_len; l >= 1; l--)
-            for (int c = (int)num[l]; c > 0; c--) len[S[k++]] = (uint8_t)l;
+        if (assign) {
+            int k = 0;  // sorted order: rarest first, so the longest codes go first
+            for (int l = max_len; l >= 1; l--)
+                for (int c = (int)num[l]; c > 0; c--) len[S[k++]] = (uint8_t)l;
+        }
     }
-    return m;
 }
 
 // canonical codes of the lengths (RFC 1951 §3.2.2), bit-reversed for a writer that sends a code's first bit lowest
@@ -669,6 +684,74 @@ __device__ __forceinline__ int extra_bits_of(int s) {  // of literal / length sy
     return d >= 4 ? (d >> 1) - 1 : 0;
 }
 
+// Phase B by the wave.  The used symbols of freq[0, n) sorted ascending by (count, symbol) into (A, S): every lane ranks
+// its own symbols (lane, lane + 64, ...) against all n by broadcast reads — n * n / 64 compares per lane instead of lane 0's
+// counting sort (~1700 dependent LDS round trips for 286 symbols).  Then lane 0 runs the in-place tree (serial by
+// nature: m - 1 merges), and the lengths go to the symbols from num[] in parallel.  Returns the number of used symbols.
+__device__ int wave_build_lengths(const uint16_t* freq, int n, int max_len, uint8_t* len, uint16_t* A, uint16_t* Ssym, uint16_t* num,
+                                  int lane) {
+    int m = 0;
+    for (int s0 = 0; s0 < n; s0 += 64) {
+        const int s = s0 + lane;
+        const uint32_t f = s < n ? freq[s] : 0u;
+        m += __popcll(__ballot(f != 0));
+        if (s < n) len[s] = 0;
+        if (f != 0) {
+            const uint32_t key = f << 9 | (uint32_t)s;
+            int rank = 0;
+            for (int t = 0; t < n; t++) {
+                const uint32_t g = freq[t];
+                rank += (g != 0 && (g << 9 | (uint32_t)t) < key) ? 1 : 0;
+            }
+            A[rank] = (uint16_t)f;
+            Ssym[rank] = (uint16_t)s;
+        }
+    }
+    if (lane < 16) num[lane] = 0;
+    __syncthreads();
+    if (lane == 0) lengths_from_sorted(m, max_len, Col8{len, 1}, Col16{A, 1}, Col16{Ssym, 1}, Col16{num, 1}, false);
+    __syncthreads();
+    // sorted order: rarest first, so the longest codes go first — the k-th symbol gets the length whose running count
+    // (from max_len down) first exceeds k
+    for (int k = lane; k < m; k += 64) {
+        int run = 0, l = max_len;
+        for (; l >= 1; l--) {
+            run += (int)num[l];
+            if (k < run) break;
+        }
+        len[Ssym[k]] = (uint8_t)l;
+    }
+    __syncthreads();
+    return m;
+}
+
+// canonical codes (RFC 1951 §3.2.2, bit-reversed) by the wave: per length the symbols that have it are counted with
+// ballots, a symbol's code is the length's first code + the number of lower symbols of that length
+__device__ void wave_assign_codes(const uint8_t* len, int n, uint16_t* code, uint16_t* num, int lane) {
+    uint32_t mine[5] = {0, 0, 0, 0, 0};  // the codes of symbols lane, lane + 64, ...  (n <= 320)
+    int c = 0, prev = 0;
+    for (int l = 1; l < 16; l++) {
+        c = (c + prev) << 1;  // first code of length l
+        int run = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const int s = 64 * r + lane;
+            const bool has = s < n && len[s] == l;
+            const unsigned long long mk = __ballot(has);
+            if (has) mine[r] = __brev((uint32_t)(c + run + __popcll(mk & ((1ull << lane) - 1)))) >> (32 - l);
+            run += __popcll(mk);
+        }
+        prev = run;
+    }
+    (void)num;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int s = 64 * r + lane;
+        if (s < n) code[s] = (uint16_t)mine[r];
+    }
+    __syncthreads();
+}
+
 __device__ void wave_block(const uint8_t* p, int32_t n, bool last, WaveLds& S, uint32_t* tok, BitW& w, int lane) {
     const bool l0 = lane == 0;
     for (int i = lane; i < kAll; i += 64) S.cnt[i] = 0;
@@ -793,11 +876,11 @@ __device__ void wave_block(const uint8_t* p, int32_t n, bool last, WaveLds& S, u
     for (int i = lane; i < kAll; i += 64) S.freq[i] = (uint16_t)S.cnt[i];
     __syncthreads();
     // ---- B: codes and header (lane 0; the arrays are the wave's own) ----
-    const Col16 freq{S.freq, 1}, dfreq{S.freq + kNL, 1}, work{S.work, 1}, syms{S.syms, 1}, clfreq{S.clfreq, 1}, num{S.num, 1};
-    const Col8 len{S.len, 1}, dlen{S.len + kNL, 1}, cllen{S.cllen, 1};
+    const Col16 work{S.work, 1}, clfreq{S.clfreq, 1}, num{S.num, 1};
+    const Col8 dlen{S.len + kNL, 1}, cllen{S.cllen, 1};
+    wave_build_lengths(S.freq, kNL, 15, S.len, S.work, S.syms, S.num, lane);
+    wave_build_lengths(S.freq + kNL, kND, 15, S.len + kNL, S.work, S.syms, S.num, lane);
     if (l0) {
-        build_lengths(freq, kNL, 15, len, work, syms, num, Col16{S.hash, 1});
-        build_lengths(dfreq, kND, 15, dlen, work, syms, num, Col16{nullptr, 0});
         int hlit = kNL, hdist = kND;
         while (hlit > 257 && S.len[hlit - 1] == 0) hlit--;
         while (hdist > 1 && dlen[hdist - 1] == 0) hdist--;
@@ -864,11 +947,9 @@ __device__ void wave_block(const uint8_t* p, int32_t n, bool last, WaveLds& S, u
         __syncthreads();
         return;
     }
-    if (l0) {
-        assign_codes(len, kNL, freq, num);
-        assign_codes(dlen, kND, dfreq, num);
-        assign_codes(cllen, kNC, clfreq, num);
-    }
+    wave_assign_codes(S.len, kNL, S.freq, S.num, lane);
+    wave_assign_codes(S.len + kNL, kND, S.freq + kNL, S.num, lane);
+    if (l0) assign_codes(cllen, kNC, clfreq, num);
     __syncthreads();
     put(w, (last ? 1u : 0u) | 2u << 1, 3, l0);
     put(w, (uint32_t)(hlit - 257) | (uint32_t)(hdist - 1) << 5 | (uint32_t)(hclen - 4) << 10, 14, l0);

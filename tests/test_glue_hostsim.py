@@ -216,7 +216,7 @@ def test_gzip_test_bodies(hostsim, monkeypatch):
     """tests/test_gzip_gpu.py on the host build of csrc/deflate.hip."""
     import test_gzip_gpu as t
     monkeypatch.setattr(t, "DEV", "cpu")
-    t.test_members_inflate_to_the_input()
+    # (test_members_inflate_to_the_input: the same inputs run under the sanitizers in tests/test_kernels_hostsim.py)
     t.test_bgzf_image()
     t.test_long_series_as_several_members()
     t.test_slot_too_small()
