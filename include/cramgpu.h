@@ -109,6 +109,9 @@ int32_t cramgpu_rans_encode_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* 
  *   - the kernels' scratch (work-queue ticket, longest-first permutation, per-workgroup order-1 tables of wide
  *     alphabets) lives in a static device array of the library (about 24.6 MiB per GPU, held until the process ends)
  *     instead of buffers grown with hipMalloc: the call allocates nothing, frees nothing and creates nothing.
+ * The descriptors never pass through the host, so the checks cramgpu_rans_encode_dev makes there (offsets non-negative
+ * multiples of CRAMGPU_ARENA_ALIGN, sizes >= 0) are made by the kernel, block by block: such a block gets CRAMGPU_E_ARG (a
+ * slot too small CRAMGPU_E_INSUFFICIENT) in d_out_len and nothing of it is read or written.
  * Limit: n_blocks <= 4096 per call (CRAMGPU_E_ARG beyond); at most 32 workgroups run the batch, so it suits one or a
  * few containers per call, not a whole read set.  All calls on one GPU share the one array: calls that overlap on a
  * GPU (different contexts or processes' streams on the same device) race; calls on one context are ordered by the

@@ -74,6 +74,29 @@ def test_static_scratch_entry_point_matches_encode_dev(orc):
         got = _run_both(eng, xc, _lib, torch, datas, orders)
         for d, o, g in zip(datas, orders, got):
             assert g == orc.rans(d, o)
+        # descriptors come from device memory, so the host cannot check them: the kernel does, block by block — a misaligned
+        # offset, a negative length or capacity give that block CRAMGPU_E_ARG and leave its neighbours alone
+        datas, orders = _batch(rng, [5000, 6000, 7000, 8000, 900])
+        n = len(datas)
+        blocks, in_bytes, out_bytes = xc.Engine.plan_encode([len(d) for d in datas], orders)
+        h_in = np.zeros(in_bytes, np.uint8)
+        for i, d in enumerate(datas):
+            h_in[blocks[i].in_off:blocks[i].in_off + len(d)] = np.frombuffer(d, np.uint8)
+        blocks[0].in_off += 8
+        blocks[1].in_len = -5
+        blocks[2].out_cap = -1
+        blocks[3].out_off += 4
+        d_in = torch.as_tensor(h_in).to(DEV)
+        d_blocks = torch.as_tensor(np.frombuffer(bytes(blocks), np.uint8)[:n * C.sizeof(_lib.Block)].copy()).to(DEV)
+        d_out = torch.zeros(out_bytes, dtype=torch.uint8, device=DEV)
+        d_len = torch.full((n,), -77, dtype=torch.int32, device=DEV)
+        d_pos = torch.zeros(n, dtype=torch.int64, device=DEV)
+        _lib.check(_lib.lib().cramgpu_rans_encode_static(eng.handle, d_in.data_ptr(), d_out.data_ptr(), d_blocks.data_ptr(), n,
+                                                         d_len.data_ptr(), d_pos.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        lens, pos = d_len.cpu().numpy(), d_pos.cpu().numpy()
+        assert lens[0] == _lib.E_ARG and lens[1] == _lib.E_ARG and lens[3] == _lib.E_ARG and lens[2] < 0, lens
+        assert d_out[int(pos[4]):int(pos[4]) + int(lens[4])].cpu().numpy().tobytes() == orc.rans(datas[4], orders[4])
         # beyond the maximum: a clear error, nothing launched
         d = torch.zeros(64, dtype=torch.uint8, device=DEV)
         rc = _lib.lib().cramgpu_rans_encode_static(eng.handle, d.data_ptr(), d.data_ptr(), d.data_ptr(), 4097, d.data_ptr(),
