@@ -757,6 +757,13 @@ class DecodeStep:
         assert torch.equal(d["cigar"][:ncg], reads.cigar[:ncg]) and torch.equal(d["aln_start"], reads.aln_start), "BAM cigar / pos"
         assert torch.equal(d["bam_flags"] & ~0x28, w["cols"].bam_flags & 0xFFD7), "BAM flags"
         self.bam_bytes = size
+        # record boundaries of the stripe on the device (cramgpu_bam_index_dev) against the offsets the encoder laid down
+        codec.index_dev(self.bam, size, 1, reads.n + 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        off, n_rec, st = codec.index_dev(self.bam, size, 1, reads.n + 1)
+        self.bam_index_ms = (time.perf_counter() - t0) * 1e3  # host clock around the call and its two scalar reads
+        assert st == 0 and n_rec == reads.n and torch.equal(off, self.rec_off), "record boundaries found on the device"
         return ("; the %d-byte BAM stripe built from them (CIGARs from features, mate restoration, BAM records) decodes back to "
                 "the reads" % size)
 
@@ -1466,7 +1473,8 @@ def main(argv=None, backend_factory=GpuBackend):
                              "per read (the uncompressed stripe handed to BGZF); outside the decode leg's time",
                     ms=bam_s * 1e3, bam_bytes=dec.bam_bytes, GBps_written=dec.bam_bytes / bam_s / 1e9,
                     reads_per_s=a.reads / bam_s,
-                    bam_decode_ms=getattr(dec, "bam_decode_ms", None))  # the stripe back into columns (BAMRecordCodec#decode)
+                    bam_decode_ms=getattr(dec, "bam_decode_ms", None),  # the stripe back into columns (BAMRecordCodec#decode)
+                    bam_index_ms=getattr(dec, "bam_index_ms", None))    # its record boundaries found on the device
                 if not a.no_bgzf and hasattr(dec, "bam_bytes"):
                     extra["decode"]["assembly"]["bgzf"] = bgzf_image(dec)
         if not a.no_full and world == 1 and dec is not None and getattr(dec, "reader", None) is not None and hasattr(step, "run_full"):

@@ -185,6 +185,7 @@ SYMBOLS = {
     "cramgpu_bam_encode_dev": (I32, [P, I32, P, P, I64, P, P, P]),
     "cramgpu_bam_decode_dev": (I32, [P, I32, P, P, P, P, P]),
     "cramgpu_bam_index": (I64, [P, I64, P, I64]),
+    "cramgpu_bam_index_dev": (I32, [P, P, I64, I32, P, I64, P, P, P]),
     "cramgpu_slice_md5_dev": (I32, [P, I32, P, P, P, P, P, P]),
     "cramgpu_gunzip_dev": (I32, [P, P, P, P, I32, P, P]),
     "cramgpu_gzip_dev": (I32, [P, P, P, P, I32, P, I32, P]),

@@ -135,6 +135,17 @@ class BAMRecordCodec:
         _lib.check(_lib.lib().cramgpu_bam_index(stripe.ctypes.data, stripe.size, off.ctypes.data, n + 1))
         return off
 
+    def index_dev(self, bam, length, n_ref, cap):
+        """Record offsets of a stripe in device memory (cramgpu_bam_index_dev).  -> (rec_off int64[cap] device tensor, number
+        of records, status); synchronises to read the two scalars."""
+        torch = _torch()
+        rec_off = torch.zeros(max(int(cap), 1), dtype=torch.int64, device=self.device)
+        count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _lib.check(_lib.lib().cramgpu_bam_index_dev(self.engine.handle, bam.data_ptr(), int(length), int(n_ref), rec_off.data_ptr(),
+                                                    int(cap), count.data_ptr(), status.data_ptr(), _stream()))
+        return rec_off, int(count.item()), int(status.item())
+
     def decode(self, bam, rec_off, bases_cap, cigar_cap):
         """bam / rec_off: device tensors.  -> dict of device tensors (the cramgpu_bam_out columns) + 'status'."""
         torch = _torch()

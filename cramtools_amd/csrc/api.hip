@@ -230,6 +230,7 @@ struct cramgpu_ctx {
     DevBuf<int32_t> d_counts;
     DevBuf<int32_t> d_list;
     DevBuf<int64_t> d_total, d_scan_ws;
+    DevBuf<int64_t> d_idx_ws;                      // cramgpu_bam_index_dev: per-segment entry / exit / base
     DevBuf<uint8_t> d_series_alias;                // cramgpu_write_series_dev: containers whose QS is not copied
     DevBuf<uint32_t> d_mate_prev;                  // cramgpu_restore_mates_dev: records pointing at a record
     DevBuf<uint8_t> d_mate_serial;                 //   containers whose chains share records
@@ -555,7 +556,7 @@ void cramgpu_close(cramgpu_ctx* c) {
     c->d_off.release(); c->d_err.release(); c->h_stage.release(); c->h_len.release(); c->h_off.release();
     c->d_mate_prev.release(); c->d_mate_serial.release();
     c->d_series_alias.release(); c->d_series_vals.release(); c->d_series_cnt.release(); c->d_series_off.release(); c->d_series_base.release();
-    c->d_counts.release(); c->d_list.release(); c->d_total.release(); c->d_scan_ws.release(); c->h_total.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
+    c->d_counts.release(); c->d_list.release(); c->d_total.release(); c->d_scan_ws.release(); c->d_idx_ws.release(); c->h_total.release(); c->d_maskws.release(); c->d_codes25.release(); c->d_prof.release();
     for (auto& sl : c->small) {
         sl.h.release();
         sl.d.release();
@@ -1741,6 +1742,25 @@ int64_t cramgpu_bgzf_index(const uint8_t* data, int64_t len, int64_t* off, int32
     }
     if (n < cap) off[n] = at;
     return n;
+}
+
+int32_t cramgpu_bam_index_dev(cramgpu_ctx* c, const uint8_t* d_bam, int64_t len, int32_t n_ref, int64_t* d_rec_off, int64_t cap,
+                              int64_t* d_count, int32_t* d_status, void* stream) {
+    if (!c || !d_bam || len < 0 || n_ref < 0 || cap < 0 || (cap > 0 && !d_rec_off) || !d_count || !d_status)
+        return fail(CRAMGPU_E_ARG, "bam_index_dev: bad argument");
+    if (len >= ((int64_t)1 << 31) * 4096) return fail(CRAMGPU_E_ARG, "bam_index_dev: stripe too long");
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    const size_t n_seg = bam_index_segments(len);
+    HIPCHK(c->d_idx_ws.reserve(3 * n_seg + 2));  // entry | exit | base (int64); counts share d_counts
+    HIPCHK(c->d_counts.reserve(n_seg + 1));
+    HIPCHK(c->d_scan_ws.reserve(feature_scan_ws_elems((int32_t)n_seg)));
+    int64_t* ws = c->d_idx_ws.p;
+    HIPCHK(launch_bam_index(d_bam, len, n_ref, d_rec_off, cap, d_count, d_status, ws, ws + n_seg, c->d_counts.p, ws + 2 * n_seg,
+                            c->d_total.p, c->d_scan_ws.p, s));
+    return 0;
 }
 
 int64_t cramgpu_bam_index(const uint8_t* bam, int64_t len, int64_t* rec_off, int64_t cap) {

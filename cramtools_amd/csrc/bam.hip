@@ -770,6 +770,178 @@ __global__ __launch_bounds__(256) void content_crc_kernel(int32_t n, int32_t n_c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Record boundaries of a BAM stripe on the device (cramgpu_bam_index_dev).  off[k + 1] = off[k] + 4 + block_size(off[k])
+// is one chain over the whole stripe (src/main/java/htsjdk/samtools/cram/paralell/Bam_OBA_Supplier.java:49-62 walks it on
+// the host, and so does cramgpu_bam_index); walked by one thread it would take a memory round trip per record.
+//   1. GUESS: the stripe is cut into segments of 4 KiB; a wave per segment looks for the first position that reads like the
+//      head of a record AND whose successor does (sizes that add up, reference ids in range, the read name's NUL where
+//      l_read_name says): almost surely the first record that starts in the segment.
+//   2. WALK: a thread per segment follows the chain from its guess to the first record start beyond the segment.
+//   3. VERIFY: one workgroup goes through the segments in order; the position the TRUE chain enters segment k at is the exit
+//      of the last segment before it that had a start (a max-scan, 1024 segments at a time).  Where the guess differs, it is
+//      replaced by the chain's position and the segment is walked again, and the scan repeated.  By induction every segment
+//      then starts from the true chain: the result does not depend on how good the guesses were, only the time does.
+//   4. counts -> offsets (scan), and a second walk writes the record offsets.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kIdxSeg = 4096;
+constexpr int64_t kIdxNone = 0x7FFFFFFFFFFFFFFFll;
+
+__device__ __forceinline__ int32_t idx_i32(const uint8_t* p) { return (int32_t)reinterpret_cast<const U32u*>(p)->v; }
+
+// does bam[o ...] read like the head of a record?  next: where its successor starts
+__device__ __forceinline__ bool idx_plausible(const uint8_t* bam, int64_t len, int64_t o, int32_t n_ref, int64_t& next) {
+    if (o + 36 > len) return false;
+    const int32_t bs = idx_i32(bam + o);
+    if (bs < 32 || o + 4 + (int64_t)bs > len) return false;
+    const int32_t ref = idx_i32(bam + o + 4), pos = idx_i32(bam + o + 8), l_seq = idx_i32(bam + o + 20);
+    const int32_t mref = idx_i32(bam + o + 24), mpos = idx_i32(bam + o + 28);
+    const int32_t l_name = bam[o + 12], n_cigar = (int32_t)bam[o + 16] | (int32_t)bam[o + 17] << 8;
+    if (ref < -1 || ref >= n_ref || mref < -1 || mref >= n_ref || pos < -1 || mpos < -1 || l_seq < 0 || l_name < 1) return false;
+    const int64_t need = 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 + (int64_t)l_seq;
+    if (need > bs) return false;
+    if (bam[o + 36 + l_name - 1] != 0) return false;
+    next = o + 4 + (int64_t)bs;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void bam_idx_guess_kernel(const uint8_t* bam, int64_t len, int32_t n_ref, int64_t n_seg,
+                                                           int64_t* entry) {
+    const int64_t k = (int64_t)blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    if (k == 0) {  // the stripe starts with a record
+        if (lane == 0) entry[0] = len > 0 ? 0 : kIdxNone;
+        return;
+    }
+    const int64_t lo = k * kIdxSeg, hi = lo + kIdxSeg < len ? lo + kIdxSeg : len;
+    int64_t found = kIdxNone;
+    for (int64_t at = lo; at < hi; at += 64) {
+        const int64_t o = at + lane;
+        int64_t nx = 0, nx2 = 0;
+        bool ok = o < hi && idx_plausible(bam, len, o, n_ref, nx);
+        if (ok && nx < len) ok = idx_plausible(bam, len, nx, n_ref, nx2);
+        const unsigned long long m = __ballot(ok);
+        if (m != 0) {
+            found = at + (__ffsll((long long)m) - 1);
+            break;
+        }
+    }
+    if (lane == 0) entry[k] = found;
+}
+
+// the chain from e to the first record start at or beyond seg_end; returns the number of records that start in between
+__device__ __forceinline__ int32_t idx_walk(const uint8_t* bam, int64_t len, int64_t e, int64_t seg_end, int64_t* exit_at,
+                                            int64_t* out, int64_t out_room, int32_t* status) {
+    int64_t o = e;
+    int32_t n = 0;
+    while (o < seg_end) {
+        bool bad = o + 4 > len;
+        int32_t bs = 0;
+        if (!bad) {
+            bs = idx_i32(bam + o);
+            bad = bs < 32 || o + 4 + (int64_t)bs > len;
+        }
+        if (bad) {  // Bam_OBA_Supplier: SAMFormatException "Invalid record length" — the chain ends here
+            *status = CRAMGPU_E_CORRUPT;
+            o = len;
+            break;
+        }
+        if (out != nullptr && n < out_room) out[n] = o;
+        n++;
+        o += 4 + (int64_t)bs;
+    }
+    *exit_at = o;
+    return n;
+}
+
+__global__ __launch_bounds__(256) void bam_idx_walk_kernel(const uint8_t* bam, int64_t len, int64_t n_seg, const int64_t* entry,
+                                                           int64_t* exit_at, int32_t* count) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_seg) return;
+    const int64_t e = entry[k];
+    int32_t scratch = 0;  // a guess may run into garbage: the last pass, over the verified chain, reports
+    if (e == kIdxNone) {
+        exit_at[k] = 0;
+        count[k] = 0;
+        return;
+    }
+    const int64_t hi = (k + 1) * kIdxSeg < len ? (k + 1) * kIdxSeg : len;
+    count[k] = idx_walk(bam, len, e, hi, &exit_at[k], nullptr, 0, &scratch);
+}
+
+__global__ __launch_bounds__(1024) void bam_idx_verify_kernel(const uint8_t* bam, int64_t len, int64_t n_seg, int64_t* entry,
+                                                              int64_t* exit_at, int32_t* count) {
+    __shared__ long long sc[1024];
+    __shared__ long long carry;   // where the chain stands in front of the chunk
+    __shared__ int first_bad;
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t k0 = 0; k0 < n_seg; k0 += 1024) {
+        for (;;) {
+            const int64_t k = k0 + tid;
+            const bool live = k < n_seg;
+            int64_t e = live ? entry[k] : kIdxNone;
+            if (live && carry >= len && e != kIdxNone) {  // the verified chain has ended (or broken off) in front of this chunk
+                entry[k] = e = kIdxNone;
+                exit_at[k] = 0;
+                count[k] = 0;
+            }
+            sc[tid] = e != kIdxNone ? exit_at[k] : 0;
+            if (tid == 0) first_bad = 1024;
+            __syncthreads();
+            for (int d = 1; d < 1024; d <<= 1) {  // inclusive max-scan
+                const long long v = tid >= d ? sc[tid - d] : 0;
+                __syncthreads();
+                if (v > sc[tid]) sc[tid] = v;
+                __syncthreads();
+            }
+            long long c = carry;
+            if (tid > 0 && sc[tid - 1] > c) c = sc[tid - 1];
+            const int64_t lo = k * kIdxSeg, hi = lo + kIdxSeg < len ? lo + kIdxSeg : len;
+            const int64_t want = (c >= lo && c < hi) ? (int64_t)c : kIdxNone;
+            if (live && e != want) atomicMin(&first_bad, tid);
+            __syncthreads();
+            const int fb = first_bad;
+            if (fb == 1024) {
+                __syncthreads();
+                if (tid == 1023 && sc[1023] > carry) carry = sc[1023];
+                __syncthreads();
+                break;
+            }
+            if (tid == fb) {  // every segment before this one is on the true chain, so `want` is where the chain enters it
+                entry[k] = want;
+                if (want == kIdxNone) {
+                    exit_at[k] = 0;
+                    count[k] = 0;
+                } else {
+                    int32_t scratch = 0;
+                    count[k] = idx_walk(bam, len, want, hi, &exit_at[k], nullptr, 0, &scratch);
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bam_idx_write_kernel(const uint8_t* bam, int64_t len, int64_t n_seg, const int64_t* entry,
+                                                            const int64_t* base, int64_t* rec_off, int64_t cap, int64_t* n_out,
+                                                            int32_t* status) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_seg) return;
+    const int64_t total = base[n_seg];
+    if (k == 0) {
+        *n_out = total;
+        if (total < cap) rec_off[total] = len;
+    }
+    const int64_t e = entry[k];
+    if (e == kIdxNone) return;
+    const int64_t hi = (k + 1) * kIdxSeg < len ? (k + 1) * kIdxSeg : len, b = base[k];
+    int64_t ex;
+    idx_walk(bam, len, e, hi, &ex, rec_off + (b < cap ? b : cap), cap > b ? cap - b : 0, status);  // the verified chain: reports
+}
+
 inline dim3 grid1(int64_t n, int per_block) { return dim3((unsigned)((n + per_block - 1) / per_block > 0 ? (n + per_block - 1) / per_block : 1)); }
 
 }  // namespace
@@ -860,5 +1032,30 @@ hipError_t launch_slice_md5(int32_t n, const uint8_t* ref, const cramgpu_refwin*
                             uint8_t* md5, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(slice_md5_kernel, grid1(n, 64), dim3(64), 0, s, n, ref, win, start, span, md5);
+    return hipGetLastError();
+}
+
+size_t bam_index_segments(int64_t len) { return (size_t)((len + kIdxSeg - 1) / kIdxSeg); }
+
+// ws_entry / ws_exit: int64[n_seg]; ws_count: int32[n_seg]; ws_base: int64[n_seg + 1]
+hipError_t launch_bam_index(const uint8_t* bam, int64_t len, int32_t n_ref, int64_t* rec_off, int64_t cap, int64_t* d_count,
+                            int32_t* d_status, int64_t* ws_entry, int64_t* ws_exit, int32_t* ws_count, int64_t* ws_base,
+                            int64_t* d_total, int64_t* d_scan_ws, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_status, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    const int64_t n_seg = (int64_t)bam_index_segments(len);
+    if (n_seg == 0) {  // an empty stripe: no record, rec_off[0] = 0
+        e = hipMemsetAsync(d_count, 0, sizeof(int64_t), s);
+        if (e == hipSuccess && cap > 0) e = hipMemsetAsync(rec_off, 0, sizeof(int64_t), s);
+        return e;
+    }
+    hipLaunchKernelGGL(bam_idx_guess_kernel, dim3((unsigned)n_seg), dim3(64), 0, s, bam, len, n_ref, n_seg, ws_entry);
+    hipLaunchKernelGGL(bam_idx_walk_kernel, grid1(n_seg, 256), dim3(256), 0, s, bam, len, n_seg, (const int64_t*)ws_entry, ws_exit,
+                       ws_count);
+    hipLaunchKernelGGL(bam_idx_verify_kernel, dim3(1), dim3(1024), 0, s, bam, len, n_seg, ws_entry, ws_exit, ws_count);
+    e = launch_feature_scan((int32_t)n_seg, ws_count, ws_base, d_total, d_scan_ws, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bam_idx_write_kernel, grid1(n_seg, 256), dim3(256), 0, s, bam, len, n_seg, (const int64_t*)ws_entry,
+                       (const int64_t*)ws_base, rec_off, cap, d_count, d_status);
     return hipGetLastError();
 }

@@ -110,6 +110,10 @@ hipError_t launch_bam_encode(int32_t n, const cramgpu_bam_cols& b, uint8_t* bam,
                              int32_t* d_sizes, int64_t* d_total, int64_t* d_scan_ws, hipStream_t s);
 hipError_t launch_bam_decode(int32_t n, const uint8_t* bam, const int64_t* rec_off, const cramgpu_bam_out& o, int32_t* status,
                              int64_t* d_total, int64_t* d_scan_ws, hipStream_t s);
+size_t bam_index_segments(int64_t len);
+hipError_t launch_bam_index(const uint8_t* bam, int64_t len, int32_t n_ref, int64_t* rec_off, int64_t cap, int64_t* d_count,
+                            int32_t* d_status, int64_t* ws_entry, int64_t* ws_exit, int32_t* ws_count, int64_t* ws_base,
+                            int64_t* d_total, int64_t* d_scan_ws, hipStream_t s);
 hipError_t launch_slice_md5(int32_t n, const uint8_t* ref, const cramgpu_refwin* win, const int32_t* start, const int32_t* span,
                             uint8_t* md5, hipStream_t s);
 hipError_t launch_gunzip(const uint8_t* in, uint8_t* out, const cramgpu_block* d_desc, int32_t n, int32_t* out_len, hipStream_t s);

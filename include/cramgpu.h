@@ -586,6 +586,16 @@ int32_t cramgpu_bam_decode_dev(cramgpu_ctx* ctx, int32_t n_reads, const uint8_t*
  * end: SAMFormatException "Invalid record length"). */
 int64_t cramgpu_bam_index(const uint8_t* bam, int64_t len, int64_t* rec_off, int64_t cap);
 
+/* The same walk for a stripe that is in device memory (e.g. BGZF members inflated by cramgpu_gunzip_dev): the inflated bytes
+ * need not visit the host to be cut into records.  The chain of block sizes is resolved in parallel — guessed record starts
+ * per 4 KiB segment, a walk per segment, then a pass that checks every segment against the chain and repairs wrong guesses,
+ * so the result is the walk's whatever the bytes look like; n_ref (reference sequences of the file; any upper bound) only
+ * sharpens the guesses.  d_rec_off[cap] receives the offsets (and the stripe length behind the last one when it fits),
+ * d_count[0] the number of records — compare with cap — and d_status[0] 0 or CRAMGPU_E_CORRUPT (a block size below 32 or
+ * past the end; the records in front of it are listed).  Stream-ordered, does not synchronise. */
+int32_t cramgpu_bam_index_dev(cramgpu_ctx* ctx, const uint8_t* d_bam, int64_t len, int32_t n_ref, int64_t* d_rec_off,
+                              int64_t cap, int64_t* d_count, int32_t* d_status, void* stream);
+
 /* =====================================================================================================
  * gunzip and gzip: htsjdk!io/ExternalCompression#gunzip (L41-48, a
  * java.util.zip.GZIPInputStream read to its end) as htsjdk!structure/Block#uncompress (L228-262) calls it for the GZIP

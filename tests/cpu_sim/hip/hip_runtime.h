@@ -198,6 +198,12 @@ inline uint32_t atomicMin(uint32_t* p, uint32_t v) {
     }
     return o;
 }
+inline int atomicMin(int* p, int v) {
+    int o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return o;
+}
 inline int atomicCAS(int* p, int expect, int v) {
     __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
     return expect;

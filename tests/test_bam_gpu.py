@@ -349,3 +349,64 @@ def test_reference_bam_record_test_inputs():
     finally:
         eng.close()
         torch.cuda.empty_cache()
+
+
+def _index_both(codec, orc, stripe, n_ref=64, cap=None):
+    want = orc.bam_index(stripe)
+    cap = len(want) if cap is None else cap
+    d = _t(np.concatenate([np.frombuffer(bytes(stripe), np.uint8), np.zeros(16, np.uint8)]))
+    rec_off, n, st = codec.index_dev(d, len(stripe), n_ref, cap)
+    assert st == 0 and n == len(want) - 1, (st, n, len(want) - 1)
+    k = min(cap, len(want))
+    assert np.array_equal(rec_off[:k].cpu().numpy(), want[:k])
+    return want
+
+
+@pytest.mark.parametrize("seed,sizes", [(0, [1]), (1, [300]), (2, [700, 5, 256, 257]), (3, [64, 1, 3000])])
+def test_record_boundaries_on_the_device(orc, seed, sizes):
+    """cramgpu_bam_index_dev against the sequential walk (oracle / Bam_OBA_Supplier.java:49-62): random stripes over many
+    4 KiB segments; records much longer than a segment; bytes that read like record heads inside tags, right where a segment
+    starts (the guess is wrong there and the verification pass must repair it); a capacity too small; a broken block size."""
+    from cramtools_amd import bam, external_compression as xc
+    rng = np.random.default_rng(500 + seed)
+    b = bc.random_batch(rng, sizes)
+    c = b["cols"]
+    cg = orc.cigars(b["read_len"], b["aln_start"], c["bam_flags"], b["feats"])
+    stripe, rec_off, status, tot = orc.bam_encode(b["ref_id"], b["aln_start"], cg["aln_end"], b["mapq"], c["bam_flags"], c["mate_flags"],
+                                                  c["mate_ref"], c["mate_start"], c["tlen"], b["read_len"], b["base_off"], b["bases"],
+                                                  b["quals"], np.ones(b["n"], np.uint8), cg["n_cigar"], cg["cigar_off"], cg["cigar"],
+                                                  names=b["names"], name_off=b["name_off"], tags=b["tags"], tag_off=b["tag_off"])
+    eng = xc.Engine(0)
+    try:
+        codec = bam.BAMRecordCodec(eng, DEV)
+        want = _index_both(codec, orc, stripe)
+        assert np.array_equal(want, rec_off)
+        _index_both(codec, orc, stripe, cap=max(1, len(want) // 2))   # too small: the count still says what is needed
+        _index_both(codec, orc, b"")                                    # an empty stripe
+        # decoys: a whole well-formed record (and its successor) as the VALUE of a B:C tag of a long record, placed so that
+        # the decoy sits exactly at a segment start
+        small = bc.py_bam_record(0, 5, 9, 4681, 0, "d", [(4 << 4)], "ACGT", b"\\5\\5\\5\\5", -1, 0, 0)
+        big = bytearray()
+        for k in range(40):
+            pad = (-(len(big) + 4 + 32 + 3 + 8)) % 4096  # tag bytes: 'XY' 'B' 'C' + count(4) in front of the value
+            value = bytes(pad) + small * 3
+            tags = b"XYBC" + len(value).to_bytes(4, "little") + value
+            big += bc.py_bam_record(1, 100 + k, 30, 4681, 16, "rn", [], "", b"", -1, 0, 0, tags)
+            big += small
+        want = _index_both(codec, orc, bytes(big))
+        assert len(want) - 1 == 80
+        # very long records (each spans several segments) between short ones
+        long_seq = "ACGT" * 5000
+        stripe2 = b"".join(bc.py_bam_record(2, 7 + i, 20, 4681, 0, "long%d" % i, [(20000 << 4)], long_seq, bytes(20000), -1, 0, 0) + small
+                           for i in range(6))
+        _index_both(codec, orc, stripe2)
+        # a block size that runs past the end: CRAMGPU_E_CORRUPT, the records in front of it are listed
+        broken = bytearray(stripe2)
+        at = int(orc.bam_index(stripe2)[7])
+        broken[at:at + 4] = (1 << 28).to_bytes(4, "little")
+        d = _t(np.concatenate([np.frombuffer(bytes(broken), np.uint8), np.zeros(16, np.uint8)]))
+        off, n, st = codec.index_dev(d, len(broken), 64, 64)
+        from cramtools_amd import _lib
+        assert st == _lib.E_CORRUPT and n == 7 and np.array_equal(off[:7].cpu().numpy(), orc.bam_index(stripe2)[:7])
+    finally:
+        eng.close()

@@ -201,6 +201,8 @@ def test_bam_test_bodies(hostsim, orc, monkeypatch):
     t.test_content_digests_match_oracle(orc, 1, [700, 256], 300)
     monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
     t.test_reference_bam_record_test_inputs()
+    t.test_record_boundaries_on_the_device(orc, 0, [1])
+    t.test_record_boundaries_on_the_device(orc, 2, [300, 5, 257])
 
 
 def test_gunzip_test_bodies(hostsim, monkeypatch):
