@@ -589,6 +589,42 @@ class DecodeStep:
             assert m[12:14] == b"BC" and zlib.decompress(m, 31) == raw, "BGZF member %d" % k
         return dict(bgzf_members=int(n), bam_bytes=int(size), bgzf_bytes=int(lens.sum()))
 
+    # ---- the way IN, Bam_OBA_Supplier.java:45-82 + BAMRecordCodec#decode: BGZF members -> records in columns ----
+    def run_ingest(self, timed):
+        """The BGZF image run_full wrote, back into record columns in one region: G (every member inflated) -> record
+        boundaries on the device -> BAM record decode.  What a BAM -> CRAM conversion does in front of K3."""
+        from cramtools_amd import bam as bam_mod
+        reads, n, size, d = self.w["reads"], self.bgzf_n, self.bam_bytes, self.bgzf_desc_h
+        tot, ncg = int(reads.bases.numel()), int(reads.cigar.numel())
+        if not hasattr(self, "ing_back"):
+            lens = self.bgzf_len[:n].cpu().numpy()
+            b = np.zeros(n, BLOCK_DTYPE)
+            b["in_off"], b["out_off"], b["in_len"], b["out_cap"] = d["out_off"][:n], d["in_off"][:n], lens, d["in_len"][:n]
+            self.ing_desc = torch.as_tensor(b.view(np.uint8).copy()).to(self.dev)
+            self.ing_back = torch.zeros(size + 16, dtype=torch.uint8, device=self.dev)
+            self.ing_len = torch.zeros(n, dtype=torch.int32, device=self.dev)
+            self.ing_codec = bam_mod.BAMRecordCodec(self.eng, self.dev)
+            self.ing_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            self.ingest_ms = []
+        if timed:
+            self.ing_ev[0].record()
+        self.eng.gunzip_dev(self.bgzf_img, self.ing_back, self.ing_desc, n, self.ing_len)
+        off, n_rec, st = self.ing_codec.index_dev(self.ing_back, size, 1, reads.n + 1)
+        assert st == 0 and n_rec == reads.n, "record boundaries of the inflated stripe"
+        self.ing_cols = self.ing_codec.decode(self.ing_back, off, tot, ncg)
+        if timed:
+            self.ing_ev[1].record()
+            torch.cuda.synchronize()
+            self.ingest_ms.append(self.ing_ev[0].elapsed_time(self.ing_ev[1]))
+
+    def verify_ingest(self):
+        reads, dd = self.w["reads"], self.ing_cols
+        tot, ncg = int(self.w["rs"].read_len.sum().item()), int(reads.n_cigar.sum().item())
+        assert int((dd["status"] != 0).sum().item()) == 0, "the inflated stripe does not parse"
+        assert torch.equal(dd["bases"][:tot], reads.bases[:tot]) and torch.equal(dd["quals"][:tot], reads.quals[:tot]), "ingest: seq / qual"
+        assert torch.equal(dd["cigar"][:ncg], reads.cigar[:ncg]) and torch.equal(dd["aln_start"], reads.aln_start), "ingest: cigar / pos"
+        return "every record of the BGZF image back in columns: bases, scores, CIGARs and starts equal the reads"
+
     def prepare(self):
         """Reader tables: where every series of every container lies (rANS series in the decoded arena, the others raw in
         the writer's arena), relative to one base address; or (round-1 form) per-read offsets of the quality bytes."""
@@ -1497,6 +1533,15 @@ def main(argv=None, backend_factory=GpuBackend):
                          "restoreReadBases / restoreQualityScores -> CIGARs, mate restoration, BAM records -> the stripe as BGZF "
                          "members (Z)", ms=df, value=w["raw_bytes"] / df / 1e3, unit="MB/s", reads_per_s=a.reads / df * 1e3,
                 **dec.verify_full())
+            dec.run_ingest(False)
+            for _ in range(a.steps):
+                dec.run_ingest(True)
+            gi = float(np.mean(dec.ingest_ms))
+            extra["ingest_full"] = dict(
+                workload="one region per step, the way in of a BAM -> CRAM conversion (Bam_OBA_Supplier.java:45-82, BAMRecordCodec"
+                         "#decode): the %d BGZF members decode_full wrote -> G -> record boundaries on the device -> BAM records "
+                         "into columns (what K3 takes)" % dec.bgzf_n, ms=gi, bam_bytes=dec.bam_bytes,
+                GBps_inflated=dec.bam_bytes / gi / 1e6, reads_per_s=a.reads / gi * 1e3, parity=dec.verify_ingest())
         if not a.no_pcie and world == 1:
             extra["pcie_inclusive"] = be.pcie(w)
             extra["pcie_inclusive"]["hw_queues"] = HW_QUEUES
