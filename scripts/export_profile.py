@@ -25,7 +25,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(p)):
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     with open(os.path.join(out, "%s_pmc_%s.csv" % (tag, c)), "w") as f:
-        f.write("# rocprofv3 --pmc %s --kernel-include-regex 'rans_encode|rans_decode|extract_|gather_copy|restore_|series_|gunzip|bam_|cigar_|mates_' -- python3 bench.py --steps 1 "
+        f.write("# rocprofv3 --pmc %s --kernel-include-regex (scripts/gpu_round.sh KERNELS) -- python3 bench.py --steps 1 "
                 "--warmup 1 --no-cpu-baseline --no-pcie ; counter unit KB per dispatch (raw, uncorrected)\n" % c)
         f.write("Kernel,Dispatches,MeanKB,MinKB,MaxKB\n")
         for k, v in agg.items():
