@@ -403,8 +403,9 @@ hipError_t launch_gunzip(const uint8_t* in, uint8_t* out, const cramgpu_block* d
     // A stream is a chain of dependent table reads and branches (~1200 cycles per symbol): throughput = streams in
     // flight / that latency.  A CU holds 32 waves, so the fewest streams per wave that still put (nearly) every stream
     // in flight at once win — 20 000 BGZF blocks: 2 per wave 81 ms, 1 per wave 88 ms (2.4 rounds), 4: 101, 8: 127, 16: 138.
+    // More members than wave slots run in rounds at 2 per wave rather than all at once at 4: the 41 828 BGZF members of the
+    // bench's stripe 131 ms at 2, 158 at 4, 190 at 8 (round 3; the launch used to widen beyond 12 288 waves).
     int lanes = 2;
-    while (lanes < 16 && (n + lanes - 1) / lanes > 12288) lanes <<= 1;
     if (forced == 2 || forced == 4 || forced == 8 || forced == 16) lanes = forced;
 #define GUNZIP_LAUNCH(L) \
     hipLaunchKernelGGL(gunzip_kernel<L>, dim3((unsigned)((n + L - 1) / L)), dim3(L), 0, s, in, out, d_desc, n, out_len)
