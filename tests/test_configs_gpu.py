@@ -1,4 +1,7 @@
-"""BASELINE.json configs[3] and configs[4] at their defining shapes ("configs_untested").
+"""BASELINE.json configs[0], configs[3] and configs[4] at their defining shapes ("configs_untested").
+
+configs[0]  the reference's own CPU-runnable case, a lossless cram + bam round trip of 100 k x 150 bp reads against 1 Mbp:
+            every device stage both ways and back in again (test_config1_bam_cram_bam_round_trip).
 
 configs[4]  lossy model R8-N40-D8 + order-1 rANS on 10 kbp reads with a high indel rate:
             (a) a container of 200 reads x 10 kbp (3 % substitutions, 4 % insertions, 4 % deletions) through
@@ -302,6 +305,54 @@ def test_config4_shard_shape(orc):
         dec.prepare()
         dec.run(True)
         assert "round-trip" in dec.verify()
+    finally:
+        eng.close()
+        torch.cuda.empty_cache()
+
+
+def test_config1_bam_cram_bam_round_trip(orc):
+    """configs[0], the reference's own CPU-runnable case — a lossless cram + bam round trip of 100 k x 150 bp reads against a
+    1 Mbp reference — with every stage on the device, both ways:
+      encode: K3 -> F3 -> setMateInfo -> data-series writer -> gzip of the non-rANS series -> rANS -> gather (+ slice MD5s,
+              content digests);
+      decode: rANS decode beside gunzip -> reader -> restoreReadBases / restoreQualityScores -> CIGARs, mate restoration, BAM
+              records -> BGZF members;
+      and back in: gunzip of those members -> record boundaries on the device -> BAM record decode.
+    The records that come out of the last step equal the reads that went into the first (bases, scores, CIGARs, starts), and
+    the rANS streams of the first container equal the oracle's coding of the writer's series."""
+    import torch
+    import bench
+    from cramtools_amd import _lib, external_compression as xc
+    n_reads, ref_len = 100_000, 1_000_000
+    eng = xc.Engine(0)
+    try:
+        w = bench.build_workload(DEV, n_reads, ref_len, 150, 0, lambda r, ref: bench.gpu_insert_bases(eng, r, ref, n_reads))
+        assert w["n_cont"] == 10
+        step = bench.Step(DEV, eng, w)
+        step.prepare_full()
+        step.run_full(True)
+        step.run_full(True)  # twice: the buffers of the first call are reused
+        info = step.verify_full()
+        assert info["gzip_members"] > 0 and info["gzip_bytes"] < info["gzip_raw_bytes"]
+        lens, pos = step.d_len.cpu().numpy(), step.d_pos.cpu().numpy()
+        assert (lens > 0).all()
+        for i, (name, order) in enumerate(bench.SERIES):  # container 0: the writer's series coded as the oracle codes them
+            if name == "QS":  # aliased (CRAMGPU_WS_ALIAS_QS): the stream is the records' quality arrays where they lie
+                raw = w["reads"].quals[:int(step.writer.lengths()[1][0, _lib.SERIES_ID["QS"]])].cpu().numpy().tobytes()
+                assert len(raw) == 150 * bench.READS_PER_CONTAINER
+            else:
+                raw = step.writer.series(0, _lib.SERIES_ID[name])
+            got = step.d_out[int(pos[i]):int(pos[i]) + int(lens[i])].cpu().numpy().tobytes()
+            assert got == orc.rans(raw, order), name
+        dec = bench.DecodeStep(DEV, eng, w, step)
+        dec.prepare()
+        dec.run_full(True)
+        assert "round-trip" in dec.verify()
+        assert "decodes back" in dec.verify_assembly()
+        out = dec.verify_full()
+        assert out["bgzf_members"] == (out["bam_bytes"] + 65279) // 65280
+        dec.run_ingest(True)
+        assert "equal the reads" in dec.verify_ingest()
     finally:
         eng.close()
         torch.cuda.empty_cache()
