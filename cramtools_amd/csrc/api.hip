@@ -126,10 +126,11 @@ struct LaunchRes {
     DevBuf<cramgpu_block> d_desc;
     DevBuf<int32_t> d_perm;
     DevBuf<uint32_t> tickets;
+    DevBuf<uint32_t> simd_arrivals;  // decoder: waves of the launch per SIMD (rans_dec.hip, first_wave_on_simd)
     uint32_t ticket_next = 0;
     DevBuf<uint8_t> enc_gs, dec_gs;
     void release() {
-        h_desc.release(); h_perm.release(); d_desc.release(); d_perm.release(); tickets.release();
+        h_desc.release(); h_perm.release(); d_desc.release(); d_perm.release(); tickets.release(); simd_arrivals.release();
         enc_gs.release(); dec_gs.release();
         if (staged) (void)hipEventDestroy(staged);
         staged = nullptr;
@@ -215,6 +216,7 @@ struct cramgpu_ctx {
     std::mutex mu;
     // rANS launch geometry
     int tab_bytes = 0, dec_tab_bytes = 0, enc_wpc = 0, dec_wpc = 0, n_waves_enc = 0, n_waves_dec = 0;
+    bool dec_roles = true;
     size_t enc_lds = 0, dec_lds = 0;
     DevBuf<uint32_t> rcp_tab;
     // descriptor staging
@@ -354,8 +356,8 @@ int rans_run(cramgpu_ctx* c, LaunchRes& r, bool encode, const uint8_t* d_in, uin
         HIPCHK(r.enc_gs.reserve((size_t)((groups + 3) & ~3) * ENC_GSCRATCH_BYTES));  // four slots to a workgroup
     else
         HIPCHK(r.dec_gs.reserve((size_t)groups * DEC_GSCRATCH_BYTES));
-    uint32_t* ticket = r.tickets.p + (r.ticket_next++ % kTicketSlots);
-    HIPCHK(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
+    uint32_t* ticket = r.tickets.p + 2 * (r.ticket_next++ % (kTicketSlots / 2));  // 8 bytes a launch (the decoder's two ends)
+    HIPCHK(hipMemsetAsync(ticket, 0, 2 * sizeof(uint32_t), s));
     RansArgs a{};
     a.in = d_in;
     a.out = d_out;
@@ -368,6 +370,12 @@ int rans_run(cramgpu_ctx* c, LaunchRes& r, bool encode, const uint8_t* d_in, uin
     a.rcp_tab = c->rcp_tab.p;
     a.tab_bytes = encode ? c->tab_bytes : c->dec_tab_bytes;
     a.prof = nullptr;
+    a.simd_arrivals = nullptr;
+    if (!encode && c->dec_roles) {
+        HIPCHK(r.simd_arrivals.reserve(DEC_SIMD_KEYS));
+        HIPCHK(hipMemsetAsync(r.simd_arrivals.p, 0, DEC_SIMD_KEYS * sizeof(uint32_t), s));
+        a.simd_arrivals = r.simd_arrivals.p;
+    }
     if (encode && c->prof_on) {  // profiling aid: per-block cycle counters, printed after a synchronising copy
         HIPCHK(c->d_prof.reserve((size_t)n * 8));
         HIPCHK(hipMemsetAsync(c->d_prof.p, 0, (size_t)n * 8 * sizeof(unsigned long long), s));
@@ -508,7 +516,8 @@ cramgpu_ctx* cramgpu_open(int32_t device_index) {
     c->dec_tab_bytes = std::max(16 * 1024, env_int("CRAMGPU_DEC_TAB_BYTES", 16 * 1024) & ~15);
     c->dec_lds = rans_decode_fixed_lds() + c->dec_tab_bytes;
     c->enc_wpc = std::max(1, std::min(env_int("CRAMGPU_ENC_GROUPS_PER_CU", 4), 4));
-    c->dec_wpc = std::max(1, std::min(env_int("CRAMGPU_DEC_WAVES_PER_CU", 5), (int)(lds_per_cu / (c->dec_lds + 512))));
+    c->dec_wpc = std::max(1, std::min(env_int("CRAMGPU_DEC_WAVES_PER_CU", 5), (int)(lds_per_cu / c->dec_lds)));
+    c->dec_roles = env_int("CRAMGPU_DEC_ROLES", 1) != 0;
     c->prof_on = env_int("CRAMGPU_PROF", 0) != 0;
     // ask for a full share of the CU's LDS so that the dispatcher cannot stack more than dec_wpc decoder waves on one
     // CU while others hold fewer: the launch lasts as long as its slowest (most crowded) chain

@@ -29,6 +29,7 @@
 //   decode: order-1 rows u32[256][256] (256 KiB)
 #define ENC_GSCRATCH_BYTES (784u * 1024u)
 #define DEC_GSCRATCH_BYTES (256u * 1024u)
+#define DEC_SIMD_KEYS 8192u  // XCD (3 bits) | shader engine, array, CU (8 bits of HW_ID) | SIMD (2 bits)
 
 struct RansArgs {
     const uint8_t* in;
@@ -38,7 +39,9 @@ struct RansArgs {
     int32_t n_blocks;
     int32_t* out_len;
     int64_t* out_pos;           // encode only
-    uint32_t* ticket;           // work-queue head, zeroed before the launch
+    uint32_t* ticket;           // work-queue head, zeroed before the launch (decode: 8 bytes, 8-byte aligned: the
+                                // blocks taken from the front and from the back of perm)
+    uint32_t* simd_arrivals;    // decode: [DEC_SIMD_KEYS] waves of this launch per SIMD, zeroed before the launch; or NULL
     uint8_t* gscratch;          // n_groups x {ENC,DEC}_GSCRATCH_BYTES
     const uint32_t* rcp_tab;    // [4096] Encoding#RansEncSymbolInit rcp_freq per freq
     int32_t tab_bytes;          // bytes of the LDS table region

@@ -22,17 +22,15 @@
 
 namespace {
 
-constexpr int kRing = 4096;  // LDS ring of compressed bytes (frequency-table parse)
 constexpr int kChunk = 16;   // decode steps between ring checks / output stores
 constexpr unsigned long long kTop = 0x8000800080008000ull;  // lane 15 of each 16-lane row: one representative per state
 
 struct DecFixedLds {
-    uint8_t ring[kRing];
     uint8_t dmap[256];
     uint8_t syml[256];
     uint8_t present[256];
-    uint16_t nsym[256];      // symbols listed by context (byte) i
-    uint32_t rowinfo[256];   // ragged rows: entry offset | 16-entry units << 24, by dense context
+    uint32_t nsym[256];      // symbols listed by context (byte) i
+    uint32_t rowinfo[256];   // ragged rows: entry offset | 16-entry units << 24, by context
     uint8_t stage[1024];     // narrow order-1 path: dense symbols of 256 steps x 4 states, flushed 16 bytes per lane
 };
 static_assert(sizeof(DecFixedLds) % 64 == 0, "tables behind the fixed part start on a 64-byte boundary");
@@ -45,60 +43,43 @@ __device__ __forceinline__ uint32_t mbcnt2(unsigned long long m1, unsigned long 
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), a);
 }
 
-// OR over the 16 lanes of a DPP row (butterfly: quad xor 1, quad xor 2, half mirror, row mirror)
-__device__ __forceinline__ uint32_t row_or(uint32_t v) {
-#ifdef HIP_SIM
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
-#else
-    // a DPP source written by the preceding vector instruction needs two wait states (the compiler cannot see into
-    // the asm, so the first s_nop is ours as well)
-    asm("s_nop 1\n\t"
-        "v_or_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_or_b32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_or_b32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_or_b32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
-        : "+v"(v));
-#endif
-    return v;
-}
-
 struct __attribute__((packed)) PackedU64 { unsigned long long v; };
 
-// reader of the frequency tables: bytes [fill-kRing, fill) of the stream are resident in the ring; the next 1 KiB
-// piece is already on its way in registers (`pre`) when a refill writes the previous one
+// Reader of the frequency tables.  The parse is one serial chain of byte-sized decisions, the same in every lane: it runs
+// on the scalar unit.  16 stream bytes at a 4-byte boundary sit in two scalar register pairs, fetched with scalar loads
+// (read only; the stream was written before the launch) and re-fetched once the cursor has moved 12 bytes or more:
+// a symbol of a table costs about 30 scalar instructions and a third of a load, where bytes fetched one at a time
+// from an LDS copy (values in vector registers, every branch an exec-mask update) cost some 600 cycles.
 struct Stream {
-    const uint8_t* src;   // 16-byte aligned start of the stream
-    int32_t len;          // stream bytes
-    int32_t fill;         // multiple of 1024
-    uint8_t* ring;
-    uint4 pre;
-    __device__ __forceinline__ void fetch() {
-        const int32_t i = fill + lane_id() * 16;
-        if (i < len) pre = *reinterpret_cast<const uint4*>(src + i);  // arena padded to 16 bytes: a partial last unit is read whole
+    const uint8_t* src;   // 16-byte aligned start of the stream (uniform)
+    int32_t len;          // stream bytes (uniform)
+    int32_t base;         // stream offset of lo's first byte (multiple of 4)
+    unsigned long long lo, hi;
+    __device__ __forceinline__ void load(int32_t p) {
+        const int32_t c = p < len ? p : len;  // the arena has 16 bytes of padding behind its last stream
+        base = c & ~3;
+#ifdef HIP_SIM
+        lo = reinterpret_cast<const PackedU64*>(src + base)->v;
+        hi = reinterpret_cast<const PackedU64*>(src + base + 8)->v;
+#else
+        typedef const __attribute__((address_space(4))) uint32_t* CPtr;
+        CPtr q = (CPtr)((unsigned long long)src + (unsigned long long)(uint32_t)base);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+        lo = ((unsigned long long)d1 << 32) | d0;
+        hi = ((unsigned long long)d3 << 32) | d2;
+#endif
     }
-    __device__ __forceinline__ void reset() {
-        __syncthreads();
-        fill = 0;
-        pre = make_uint4(0, 0, 0, 0);
-        fetch();
-    }
-    __device__ __forceinline__ void refill() {
-        const int32_t pos = (fill & (kRing - 1)) + lane_id() * 16;
-        *reinterpret_cast<uint4*>(ring + pos) = pre;
-        fill += 1024;
-        fetch();
-        __syncthreads();
-    }
-    // byte at stream offset p (uniform p), sequential access
-    __device__ __forceinline__ uint32_t at(int32_t p) {
-        while (p >= fill) refill();
-        return ring[p & (kRing - 1)];
+    // at least 5 stream bytes starting at offset p (first one lowest); p < len
+    __device__ __forceinline__ unsigned long long at5(int32_t p) {
+        uint32_t off = (uint32_t)(p - base);
+        if (off > 11u) {
+            load(p);
+            off = (uint32_t)(p - base);
+        }
+        const uint32_t sh = 8u * (off & 7u);
+        const unsigned long long a = off < 8u ? lo : hi;
+        const unsigned long long b = off < 8u ? hi : 0ull;
+        return sh != 0 ? (a >> sh) | (b << (64u - sh)) : a;
     }
 };
 
@@ -195,33 +176,42 @@ __device__ __forceinline__ uint32_t row_push(uint32_t keep, uint32_t v) {
 }
 
 // Frequencies#readStats_o0 L13-46: one row.  V::sym(j, F, C) is called per listed symbol.  Returns 0 or a code.
+// A listed symbol takes at most 4 bytes (a two-byte frequency, the next symbol, a run length).  The reference reads 16
+// bytes of states behind the tables, so a table that comes within 4 bytes of the stream's end is a failure there too.
 template <bool O1, class V>
 __device__ __forceinline__ int read_row(Stream& S, int32_t& p, V& v) {
     int rle = 0, x = 0;
     if (p >= S.len) return CRAMGPU_E_CORRUPT;
-    int j = (int)S.at(p++);
+    int j = (int)(S.at5(p) & 255u);
+    p++;
     do {
-        if (p >= S.len) return CRAMGPU_E_CORRUPT;
-        int F = (int)S.at(p++);
+        if (p + 4 > S.len) return CRAMGPU_E_CORRUPT;
+        unsigned long long w = S.at5(p);
+        int F = (int)(w & 255u);
         if (F >= 128) {
-            if (p >= S.len) return CRAMGPU_E_CORRUPT;
-            F = ((F & 127) << 8) | (int)S.at(p++);
+            F = ((F & 127) << 8) | (int)((w >> 8) & 255u);
+            w >>= 16;
+            p += 2;
+        } else {
+            w >>= 8;
+            p += 1;
         }
         if (O1 && F == 0) F = RANS_TOTFREQ;
         if (x + F > RANS_TOTFREQ) return CRAMGPU_E_CORRUPT;
         v.sym(j, F, x);
         x += F;
-        if (p >= S.len) return CRAMGPU_E_CORRUPT;
-        if (rle == 0 && j + 1 == (int)S.at(p)) {
-            j = (int)S.at(p++);
-            if (p >= S.len) return CRAMGPU_E_CORRUPT;
-            rle = (int)S.at(p++);
+        const int nx = (int)(w & 255u);
+        if (rle == 0 && j + 1 == nx) {
+            j = nx;
+            rle = (int)((w >> 8) & 255u);
+            p += 2;
         } else if (rle != 0) {
             rle--;
             j++;
             if (j > 255) return CRAMGPU_E_CORRUPT;
         } else {
-            j = (int)S.at(p++);
+            j = nx;
+            p++;
         }
     } while (j != 0);
     return 0;
@@ -232,22 +222,26 @@ template <class V>
 __device__ __forceinline__ int read_rows_o1(Stream& S, int32_t& p, V& v) {
     int rle = 0;
     if (p >= S.len) return CRAMGPU_E_CORRUPT;
-    int i = (int)S.at(p++);
+    int i = (int)(S.at5(p) & 255u);
+    p++;
     do {
         v.ctx(i);
         int rc = read_row<true>(S, p, v);
         if (rc) return rc;
-        if (p >= S.len) return CRAMGPU_E_CORRUPT;
-        if (rle == 0 && i + 1 == (int)S.at(p)) {
-            i = (int)S.at(p++);
-            if (p >= S.len) return CRAMGPU_E_CORRUPT;
-            rle = (int)S.at(p++);
+        if (p + 2 > S.len) return CRAMGPU_E_CORRUPT;
+        const unsigned long long w = S.at5(p);
+        const int nx = (int)(w & 255u);
+        if (rle == 0 && i + 1 == nx) {
+            i = nx;
+            rle = (int)((w >> 8) & 255u);
+            p += 2;
         } else if (rle != 0) {
             rle--;
             i++;
             if (i > 255) return CRAMGPU_E_CORRUPT;
         } else {
-            i = (int)S.at(p++);
+            i = nx;
+            p++;
         }
     } while (i != 0);
     return 0;
@@ -262,25 +256,31 @@ struct FillO0 {
 };
 struct MarkO1 {
     uint8_t* present;
-    uint16_t* nsym;
+    uint32_t* nsym;
     int cur;
+    uint32_t cnt;  // symbols of the current row so far (uniform)
+    __device__ __forceinline__ void finish() {
+        if (cnt != 0 && lane_id() == 0) atomicAdd(&nsym[cur], cnt);  // a context listed twice (corrupt) adds up
+        cnt = 0;
+    }
     __device__ __forceinline__ void ctx(int i) {
+        finish();
         present[i] = 1;
         cur = i;
     }
     __device__ __forceinline__ void sym(int j, int, int) {
         present[j] = 1;
-        if (lane_id() == 0 && nsym[cur] < 256) nsym[cur]++;
+        cnt++;
     }
 };
 // Ragged rows for wide alphabets: a context's row lists only the symbols it has, padded to a multiple of 16 with
 // copies of its first entry (a 200-symbol ITF8 series has ~3 symbols in most contexts: 13 tests per step become 1-2,
-// and the rows fit LDS).
+// and the rows fit LDS).  Symbols and contexts are byte values here (rowinfo is indexed by the byte, the symbol table
+// is the identity): a listed symbol's entry is made of scalars alone and leaves as one store.
 struct FillRagged {
     uint32_t* rows;
-    const uint8_t* dmap;
     const uint32_t* rowinfo;
-    uint32_t cur, cap, fill, first;
+    uint32_t cur, cap, fill, first;  // uniform
     __device__ __forceinline__ void finish() {
         if (fill > 0)
             for (uint32_t q = fill + (uint32_t)lane_id(); q < cap; q += 64) rows[cur + q] = first;
@@ -288,29 +288,29 @@ struct FillRagged {
     }
     __device__ __forceinline__ void ctx(int i) {
         finish();
-        const uint32_t info = rowinfo[dmap[i]];
+        const uint32_t info = (uint32_t)UNIFORM(rowinfo[i]);
         cur = info & 0xFFFFFFu;
         cap = 16u * (info >> 24);
     }
     __device__ __forceinline__ void sym(int j, int F, int C) {
-        const uint32_t e = ((4096u - (uint32_t)C) & 4095u) | ((uint32_t)dmap[j] << 12) | ((uint32_t)(F - 1) << 20);
+        const uint32_t e = (((4096u - (uint32_t)C) & 4095u) << 20) | ((uint32_t)(F - 1) << 8) | (uint32_t)j;
         if (fill == 0) first = e;
         if (lane_id() == 0 && fill < cap) rows[cur + fill] = e;
         fill++;
     }
 };
 struct FillO1 {
-    uint32_t* rows;  // [nd][stride]: (4096 - C) & 4095 | k << 12 | (F-1) << 20, see decode_o1
+    uint32_t* rows;  // [nd][stride]: (4096 - C) & 4095 << 20 | (F-1) << 8 | k, see decode_o1
     const uint8_t* dmap;
     int stride;
     int cur;
     __device__ __forceinline__ void ctx(int i) { cur = dmap[i] * stride; }
     __device__ __forceinline__ void sym(int j, int F, int C) {
         if (lane_id() == 0)
-            rows[cur + dmap[j]] = ((4096u - (uint32_t)C) & 4095u) | ((uint32_t)dmap[j] << 12) | ((uint32_t)(F - 1) << 20);
+            rows[cur + dmap[j]] = (((4096u - (uint32_t)C) & 4095u) << 20) | ((uint32_t)(F - 1) << 8) | (uint32_t)dmap[j];
     }
 };
-constexpr uint32_t kAbsent = 0xFFFFFFFFu;  // not a valid entry: it would be C = 1 with F = 4096
+constexpr uint32_t kAbsent = 0xFFFFFFFFu;  // not a valid entry: it would be C = 1 with F = 4096 (and loses every minimum)
 
 // rows[nd][stride] <- kAbsent
 __device__ __forceinline__ void rows_clear(uint32_t* rows, int total) {
@@ -377,11 +377,30 @@ __device__ __forceinline__ int decode_o0(Stream& S, int32_t p, const uint32_t* R
     return 0;
 }
 
+// unsigned minimum over a 16-lane row (SMALL: lanes 8..15 mirror lanes 0..7, three stages)
+template <bool SMALL>
+__device__ __forceinline__ uint32_t row_min(uint32_t v) {
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v = t < v ? t : v;
+    if (!SMALL) {
+        t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
 // D14#uncompress L9-70.  rows[nd][16*M] over the dense alphabet (index 0 = byte 0); an entry is
-//   (4096 - C) & 4095 | k << 12 | (F-1) << 20
-// so that with xa = x + entry the slot offset inside the symbol is xa & 4095 and the slot belongs to the symbol iff
-// (xa << 20) <= entry (C + F <= 4096 keeps a slot below C from aliasing).  Lane s of a state's row tests the symbols
-// s, s+16, ...; symbols a context does not have carry a copy of one it has, so every hit ORs to the same word.
+//   (4096 - C) & 4095 << 20 | (F-1) << 8 | k
+// so that v = (x << 20) + entry carries (slot - C) mod 4096 in its top 12 bits.  The slot belongs to the symbol with the
+// largest C <= slot, whose slot - C is the smallest of the row (a symbol with C > slot wraps to 4096 - (C - slot), which
+// is larger): the unsigned minimum of the row's v is the winner's word, slot - C on top, F-1 and the symbol below.  Lane
+// s of a state's row takes the minimum over the symbols s, s+16, ... (two instructions per entry), an unsigned-min
+// butterfly over the row does the rest.  Symbols a context does not have carry a copy of one it has.
 // MS > 0: square rows[nd][16*MS], MS known at compile time (the next row is fetched while the state renormalises).
 // MS == 0: ragged rows (FillRagged): rowinfo[k] = entry offset | 16-entry units << 24 of context k's row.
 template <int MS>
@@ -399,39 +418,44 @@ __device__ __forceinline__ int decode_o1(Stream& S, int32_t p, const uint32_t* r
     const int32_t q = n >> 2;
     uint32_t e[MS > 0 ? MS : 1];
     uint32_t roff = (uint32_t)s;  // context 0
-    uint32_t Mc = 1;               // ragged: 16-entry units of this state's current row
+    uint32_t Ml = 0;               // ragged: index of the last 16-entry unit of this state's current row
     if (MS > 0) {
 #pragma unroll
         for (int m = 0; m < MS; m++) e[m] = rows[roff + 16 * m];
     } else {
         const uint32_t info = rowinfo[0];
         roff = (info & 0xFFFFFFu) + (uint32_t)s;
-        Mc = info >> 24;
+        Ml = (info >> 24) - 1u;
     }
     auto step = [&](bool live) -> uint32_t {
-        uint32_t pk = 0;
+        const uint32_t xs = x << 20;
+        uint32_t v;
         if (MS > 0) {
+            v = xs + e[0];
 #pragma unroll
-            for (int m = 0; m < MS; m++) {
-                const uint32_t xa = x + e[m];
-                pk |= (xa << 20) <= e[m] ? ((e[m] & ~4095u) | (xa & 4095u)) : 0u;
+            for (int m = 1; m < MS; m++) {
+                const uint32_t t = xs + e[m];
+                v = t < v ? t : v;
             }
         } else {
             // up to the longest row of the four states, four entries per round trip; an index past a row's end
-            // repeats its last entry, which ORs to the same word
-            for (uint32_t m = 0; __ballot(m < Mc) != 0; m += 4) {
-                uint32_t em[4];
+            // repeats its last unit, which leaves the minimum as it is
+            v = xs + rows[roff];
+            if (__ballot(Ml != 0u) != 0) {
+                for (uint32_t m = 1; __ballot(m <= Ml) != 0; m += 4) {
+                    uint32_t em[4];
 #pragma unroll
-                for (uint32_t c = 0; c < 4; c++) em[c] = rows[roff + 16u * (m + c < Mc ? m + c : Mc - 1u)];
+                    for (uint32_t c = 0; c < 4; c++) em[c] = rows[roff + 16u * (m + c < Ml ? m + c : Ml)];
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const uint32_t xa = x + em[c];
-                    pk |= (xa << 20) <= em[c] ? ((em[c] & ~4095u) | (xa & 4095u)) : 0u;
+                    for (int c = 0; c < 4; c++) {
+                        const uint32_t t = xs + em[c];
+                        v = t < v ? t : v;
+                    }
                 }
             }
         }
-        pk = row_or(pk);
-        const uint32_t k = (pk >> 12) & 255u;
+        v = row_min<false>(v);
+        const uint32_t k = v & 255u;
         if (live) {
             if (MS > 0) {
                 roff = k * stride + (uint32_t)s;
@@ -440,9 +464,9 @@ __device__ __forceinline__ int decode_o1(Stream& S, int32_t p, const uint32_t* r
             } else {
                 const uint32_t info = rowinfo[k];
                 roff = (info & 0xFFFFFFu) + (uint32_t)s;
-                Mc = info >> 24;
+                Ml = (info >> 24) - 1u;
             }
-            x = ((pk >> 20) + 1u) * (x >> 12) + (pk & 4095u);
+            x = (((v >> 8) & 4095u) + 1u) * (x >> 12) + (v >> 20);
         }
         renorm(x, cur, curv, w, P, live);
         return k;
@@ -515,22 +539,6 @@ __device__ __forceinline__ void narrow_fix(uint32_t* ent, int nsl, int ctx_strid
         for (int j = 0; j < nsl; j++)
             if (ent[c * ctx_stride + j * sym_stride] == kAbsent) ent[c * ctx_stride + j * sym_stride] = first;
     }
-}
-
-template <bool SMALL>
-__device__ __forceinline__ uint32_t row_min(uint32_t v) {
-    uint32_t t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
-    v = t < v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
-    v = t < v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
-    v = t < v ? t : v;
-    if (!SMALL) {
-        t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
-        v = t < v ? t : v;
-    }
-    return v;
 }
 
 struct __attribute__((packed)) PackedU128 { uint32_t a, b, c, d; };
@@ -795,8 +803,7 @@ __device__ __forceinline__ void decode_block(const RansArgs& a, int b, uint8_t* 
             else
                 __builtin_amdgcn_s_setprio(0);
 #endif
-            Stream S{src, len, 0, L->ring, make_uint4(0, 0, 0, 0)};
-            S.reset();
+            Stream S{uniform_ptr(src), UNIFORM(len), -64, 0ull, 0ull};
             int32_t p = 9;
             int rc;
             if (order == 0) {
@@ -813,31 +820,34 @@ __device__ __forceinline__ void decode_block(const RansArgs& a, int b, uint8_t* 
                     L->nsym[i] = 0;
                 }
                 __syncthreads();
-                MarkO1 mk{L->present, L->nsym, 0};
+                MarkO1 mk{L->present, L->nsym, 0, 0};
                 int32_t p1 = p;
                 rc = read_rows_o1(S, p1, mk);
+                mk.finish();
                 __syncthreads();
                 if (!rc) {
-                    // dense alphabet in byte order, byte 0 first; ragged row geometry alongside
+                    // dense alphabet in byte order, byte 0 first; ragged row geometry (by byte) alongside: 64 bytes a
+                    // round, rank and row offset from a ballot and a prefix sum over the lanes
                     int nd = 0, total = 0;
-                    if (l == 0) {
-                        for (int j = 0; j < 256; j++) {
-                            if (L->present[j]) {
-                                const int units = L->nsym[j] ? (L->nsym[j] + 15) >> 4 : 1;
-                                L->rowinfo[nd] = (uint32_t)total | ((uint32_t)units << 24);
-                                total += 16 * units;
-                                L->dmap[j] = (uint8_t)nd;
-                                L->syml[nd] = (uint8_t)j;
-                                nd++;
-                            } else {
-                                L->dmap[j] = 0;
-                            }
+                    for (int j0 = 0; j0 < 256; j0 += 64) {
+                        const int j = j0 + l;
+                        const bool pres = L->present[j] != 0;
+                        const uint32_t ns = L->nsym[j] < 256u ? L->nsym[j] : 256u;
+                        const int units = !pres ? 0 : ns ? (int)((ns + 15u) >> 4) : 1;
+                        const unsigned long long m = __ballot(pres);
+                        const int rank = nd + __popcll(m & ((1ull << l) - 1ull));
+                        int incl = units;
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const int t = __shfl_up(incl, d);
+                            if (l >= d) incl += t;
                         }
+                        L->rowinfo[j] = pres ? (uint32_t)(total + 16 * (incl - units)) | ((uint32_t)units << 24) : (1u << 24);
+                        L->dmap[j] = pres ? (uint8_t)rank : (uint8_t)0;
+                        if (pres) L->syml[rank] = (uint8_t)j;
+                        nd += __popcll(m);
+                        total += 16 * __shfl(incl, 63);
                     }
-                    nd = __shfl(nd, 0);
-                    total = __shfl(total, 0);
                     __syncthreads();
-                    S.reset();
                     if (nd <= 16) {  // narrow tables: 8 x 8 or 16 x 16 words
                         const bool small = nd <= 8;
                         const int nsl = small ? 8 : 16;
@@ -871,11 +881,12 @@ __device__ __forceinline__ void decode_block(const RansArgs& a, int b, uint8_t* 
                         }
                     } else {  // ragged rows, in LDS when they fit (total <= 256 * 256 entries = the global scratch)
                         const bool in_lds = total * 4 <= a.tab_bytes;
+                        for (int i = l; i < 256; i += 64) L->syml[i] = (uint8_t)i;  // ragged rows carry byte values
                         if (in_lds) {
                             uint32_t* r = reinterpret_cast<uint32_t*>(tab);
                             for (int i = l; i < total; i += 64) r[i] = 0;
                             __syncthreads();
-                            FillRagged v{r, L->dmap, L->rowinfo, 0, 0, 0, 0};
+                            FillRagged v{r, L->rowinfo, 0, 0, 0, 0};
                             rc = read_rows_o1(S, p, v);
                             v.finish();
                             __syncthreads();
@@ -885,7 +896,7 @@ __device__ __forceinline__ void decode_block(const RansArgs& a, int b, uint8_t* 
                             for (int i = l; i < total; i += 64) r[i] = 0;
                             __threadfence();
                             __syncthreads();
-                            FillRagged v{r, L->dmap, L->rowinfo, 0, 0, 0, 0};
+                            FillRagged v{r, L->rowinfo, 0, 0, 0, 0};
                             rc = read_rows_o1(S, p, v);
                             v.finish();
                             __threadfence();
@@ -901,15 +912,45 @@ __device__ __forceinline__ void decode_block(const RansArgs& a, int b, uint8_t* 
     if (l == 0) a.out_len[b] = result;
 }
 
+// A launch mixes a few long chains (a quality block of a container: 25 ms) with many short ones, and a SIMD shared by
+// two busy waves runs each of them slower.  The launch lasts as long as its slowest long chain, so the short blocks must
+// not pile up beside some of the long ones: the first wave of the launch on a SIMD takes blocks from the front of the
+// longest-first permutation, every later wave on that SIMD from its back, and with two waves per SIMD the short
+// blocks spread over all SIMDs evenly.  One 64-bit counter holds both ends (blocks taken from the front in the low
+// word, from the back in the high word): a ticket is good while their sum is below the number of blocks, so the two
+// ends meet without handing a block out twice, and a wave whose end has run dry simply works from the other side.
+__device__ __forceinline__ bool first_wave_on_simd(uint32_t* arrivals) {
+#ifdef HIP_SIM
+    (void)arrivals;
+    return true;
+#else
+    if (arrivals == nullptr) return true;
+    const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: SIMD 5:4, CU/SH/SE 15:8
+    const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
+    const uint32_t key = ((xcc & 7u) << 10) | (((hw >> 8) & 255u) << 2) | ((hw >> 4) & 3u);
+    uint32_t rank = 0;
+    if (threadIdx.x == 0) rank = atomicAdd(&arrivals[key], 1u);
+    return __shfl(rank, 0) == 0;
+#endif
+}
+
 __global__ __launch_bounds__(64) void rans_decode_kernel(RansArgs a) {
     CRAMGPU_DYN_LDS(smem);
     uint8_t* gs = a.gscratch + (size_t)blockIdx.x * DEC_GSCRATCH_BYTES;
+    unsigned long long* ends = reinterpret_cast<unsigned long long*>(a.ticket);
+    const bool front = first_wave_on_simd(a.simd_arrivals);
+    const uint32_t n = (uint32_t)a.n_blocks;
     for (;;) {
-        uint32_t t = 0;
-        if (threadIdx.x == 0) t = atomicAdd(a.ticket, 1u);
-        t = __shfl(t, 0);
-        if (t >= (uint32_t)a.n_blocks) break;
-        decode_block(a, a.perm[t], smem, gs);
+        uint32_t head = 0, tail = 0;
+        if (threadIdx.x == 0) {
+            const unsigned long long prev = atomicAdd(ends, front ? 1ull : (1ull << 32));
+            head = (uint32_t)prev;
+            tail = (uint32_t)(prev >> 32);
+        }
+        head = __shfl(head, 0);
+        tail = __shfl(tail, 0);
+        if (head >= n || tail >= n || head + tail >= n) break;
+        decode_block(a, a.perm[front ? head : n - 1u - tail], smem, gs);
         __syncthreads();
     }
 }
