@@ -19,6 +19,8 @@
 namespace {
 
 struct __attribute__((packed)) W32u { uint32_t v; };
+struct __attribute__((packed)) W16u { uint16_t v; };
+struct __attribute__((packed)) W128u { uint32_t a, b, c, d; };
 
 constexpr int kMaxLanes = 16;
 constexpr int kLitSyms = 288, kDistSyms = 32, kLenCodes = 19;
@@ -283,7 +285,39 @@ __device__ int inflate_stream(Bits& b, Tables& T, uint8_t* out, int32_t cap, int
                         uint8_t* d = out + o;
                         const uint8_t* s = d - dist;
                         int i = 0;
-                        if (dist >= 4) {
+                        if (dist >= 16) {
+                            // A stream waits for memory more than for anything else, and a copy in 4-byte and 1-byte turns
+                            // is a round trip per turn (the next load may depend on the last store: 4 + 3 of them for 19
+                            // bytes).  At distance >= 16 the source of a 16-byte piece lies wholly behind its destination:
+                            // one load, then the stores.  The last piece reads up to 15 bytes past the match's source —
+                            // bytes this stream wrote before d + i.
+                            for (; i + 16 <= len; i += 16) *reinterpret_cast<W128u*>(d + i) = *reinterpret_cast<const W128u*>(s + i);
+                            const int r = len - i;
+                            if (r > 0) {
+                                const W128u v = *reinterpret_cast<const W128u*>(s + i);
+                                uint8_t* q = d + i;
+                                uint32_t w = v.a;
+                                if (r >= 4) {
+                                    reinterpret_cast<W32u*>(q)->v = v.a;
+                                    w = v.b;
+                                }
+                                if (r >= 8) {
+                                    reinterpret_cast<W32u*>(q + 4)->v = v.b;
+                                    w = v.c;
+                                }
+                                if (r >= 12) {
+                                    reinterpret_cast<W32u*>(q + 8)->v = v.c;
+                                    w = v.d;
+                                }
+                                q += r & ~3;
+                                if (r & 2) {
+                                    reinterpret_cast<W16u*>(q)->v = (uint16_t)w;
+                                    w >>= 16;
+                                    q += 2;
+                                }
+                                if (r & 1) *q = (uint8_t)w;
+                            }
+                        } else if (dist >= 4) {
                             for (; i + 4 <= len; i += 4) reinterpret_cast<W32u*>(d + i)->v = reinterpret_cast<const W32u*>(s + i)->v;
                             for (; i < len; i++) d[i] = s[i];
                         } else {

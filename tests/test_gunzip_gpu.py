@@ -46,7 +46,12 @@ def _corpus(rng):
     noise = rng.integers(0, 256, 40000).astype(np.uint8).tobytes()
     runs = b"".join(bytes([int(c)]) * int(k) for c, k in zip(rng.integers(0, 256, 300), rng.integers(1, 600, 300)))
     names = b"".join(b"read.%d/%d\t" % (i, i % 7) for i in range(4000))
-    return [b"", b"a", b"abc" * 5, acgt, quals, noise, runs, names, acgt[:257], bytes(1000), noise[:5]]
+    # matches of every length 3..258 (the copy works in 16-byte pieces with a tail of 0..15 bytes), far and near: periods
+    # around the 16-byte limit below which the copy goes in 4-byte turns
+    seed = noise[:600]
+    every_len = seed + b"".join(seed[L % 37:L % 37 + L] + bytes([L & 255, (L * 7) & 255]) for L in range(3, 259))
+    periods = b"".join(seed[k:2 * k] * (3 + k % 5) + seed[:k % 7] for k in range(4, 40))
+    return [b"", b"a", b"abc" * 5, acgt, quals, noise, runs, names, acgt[:257], bytes(1000), noise[:5], every_len, periods]
 
 
 def test_gunzip_matches_zlib():
