@@ -199,8 +199,11 @@ class Step:
         self.writer = rec.Writer(eng, dev, w["n_cont"], w["d_in"].numel() + 40 * w["reads"].n + 16 * w["feat_cap"] +
                                  512 * w["n_cont"]) if writer else None
         self.ids = np.array([_lib.SERIES_ID[name] for name, _ in SERIES])
+        self.orders = np.array([o for _, o in SERIES], np.int32)
         self.blk = np.zeros(n, BLOCK_DTYPE)
-        self.blk["order"] = np.tile(np.array([o for _, o in SERIES], np.int32), w["n_cont"])
+        self.blk["order"] = np.tile(self.orders, w["n_cont"])
+        self.d_blk = torch.zeros(32 * n, dtype=torch.uint8, device=dev)  # the block table cramgpu_rans_encode_series_dev makes
+        self.d_blk_status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.d_out = torch.empty(w["out_bytes"], dtype=torch.uint8, device=dev)
         self.d_len = torch.zeros(n, dtype=torch.int32, device=dev)
         self.d_pos = torch.zeros(n, dtype=torch.int64, device=dev)
@@ -227,26 +230,23 @@ class Step:
         self.fac.matrices_and_codes(reads, self.feats, self.hist, self.mats)  # F3 on the device, stream-ordered
         d_in, blocks = w["d_in"], w["blocks"]
         if self.writer is not None:
-            # W: records + features -> the byte streams of every series; stream lengths back to the host (as the
-            # container headers need them anyway), block descriptors from them
+            # W: records + features -> the byte streams of every series, then K1 straight behind it: the block table
+            # (stream of series k of container c, its slot of RANS#allocateIfNeeded's size) and its longest-first order
+            # are made on the device (cramgpu_rans_encode_series_dev), so nothing comes back to the host between the two
+            # (the lengths went to the host and the table back up before: ~1 ms of an idle GPU per step).
+            # Aliased QS streams lie in reads.quals (CRAMGPU_WS_ALIAS_QS): all offsets rebased on the lower address.
             self.writer.write(reads, w["cols"], self.feats)
-            off, ln = self.writer.lengths()
-            blk = self.blk
-            blk["in_off"], blk["in_len"] = off[:, self.ids].reshape(-1), ln[:, self.ids].reshape(-1)
-            cap = (1.05 * blk["in_len"].astype(np.float64) + 257.0 * 257.0 * 3.0 + 4.0).astype(np.int32)  # RANS#allocateIfNeeded
-            blk["out_cap"] = cap
-            slot = (cap.astype(np.int64) + 15) // 16 * 16
-            blk["out_off"] = np.cumsum(slot) - slot
-            assert int(blk["out_off"][-1] + slot[-1]) + 16 <= self.d_out.numel()
-            # aliased QS streams lie in reads.quals (CRAMGPU_WS_ALIAS_QS): all offsets rebased on the lower address
             p_arena = self.writer.arena.data_ptr()
             base = min(p_arena, reads.quals.data_ptr()) & ~15
-            blk["in_off"] += p_arena - base
-            d_in, blocks = base, blk
-        # K1 + gather
-        if timed:
-            self.ev[0].record()
-        self.eng.encode_dev(d_in, self.d_out, blocks, w["n_blocks"], self.d_len, self.d_pos)
+            if timed:
+                self.ev[0].record()
+            self.eng.encode_series_dev(base, p_arena - base, self.writer.off, self.writer.len, self.writer.status, w["n_cont"],
+                                       self.ids, self.orders, self.d_out, self.d_blk, self.d_len, self.d_pos, self.d_blk_status)
+        else:
+            # K1 over the workload's own arena (round-1 form)
+            if timed:
+                self.ev[0].record()
+            self.eng.encode_dev(d_in, self.d_out, blocks, w["n_blocks"], self.d_len, self.d_pos)
         if timed:
             self.ev[1].record()
         self.eng.gather_dev(self.d_out, self.d_pos, self.d_len, w["n_blocks"], w["max_cap"], self.d_pack, self.d_pack_off)
@@ -1457,6 +1457,9 @@ def main(argv=None, backend_factory=GpuBackend):
     # parity verdict on this rank's blocks: no negative lengths, and the sampled containers equal the CPU oracle
     lens = step.d_len.cpu().numpy()
     assert (lens >= 0).all(), "a block failed to encode: %r" % (lens[lens < 0][:8],)
+    if getattr(step, "writer", None) is not None:
+        step.writer.lengths()  # raises what the writer reported
+        assert int(step.d_blk_status.item()) == 0, "the block table made on the device: status %d" % int(step.d_blk_status.item())
     comp_bytes = int(lens[lens > 0].sum())
     extra = {}
     line = None

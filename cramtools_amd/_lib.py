@@ -49,6 +49,15 @@ class Block(C.Structure):
                 ("order", C.c_int32), ("reserved", C.c_int32)]
 
 
+def _block_dtype():
+    import numpy as np
+    return np.dtype([("in_off", np.int64), ("out_off", np.int64), ("in_len", np.int32), ("out_cap", np.int32),
+                     ("order", np.int32), ("reserved", np.int32)])
+
+
+BLOCK_DTYPE = _block_dtype()  # cramgpu_block as a numpy record (block tables read back from the device)
+
+
 class RefWin(C.Structure):
     _fields_ = [("ref_off", C.c_int64), ("ref_len", C.c_int64), ("ref_start0", C.c_int64)]
 
@@ -144,6 +153,7 @@ SYMBOLS = {
     "cramgpu_rans_raw_size": (I32, [P, I32]),
     "cramgpu_rans_encode_dev": (I32, [P, P, P, P, I32, P, P, P]),
     "cramgpu_rans_encode_static": (I32, [P, P, P, P, I32, P, P, P]),
+    "cramgpu_rans_encode_series_dev": (I32, [P, P, I64, P, P, P, I32, P, P, I32, P, I64, P, P, P, P, P]),
     "cramgpu_rans_decode_dev": (I32, [P, P, P, P, I32, P, P]),
     "cramgpu_gather_dev": (I32, [P, P, P, P, I32, I32, I32, P, I64, P, P]),
     "cramgpu_rans_encode_batch": (I32, [P, P, I64, P, I64, P, I32, P]),

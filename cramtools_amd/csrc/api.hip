@@ -127,10 +127,11 @@ struct LaunchRes {
     DevBuf<int32_t> d_perm;
     DevBuf<uint32_t> tickets;
     DevBuf<uint32_t> simd_arrivals;  // decoder: waves of the launch per SIMD (rans_dec.hip, first_wave_on_simd)
+    DevBuf<uint8_t> sort_ws;         // cramgpu_rans_encode_series_dev: workspace of the longest-first sort on the device
     uint32_t ticket_next = 0;
     DevBuf<uint8_t> enc_gs, dec_gs;
     void release() {
-        h_desc.release(); h_perm.release(); d_desc.release(); d_perm.release(); tickets.release(); simd_arrivals.release();
+        h_desc.release(); h_perm.release(); d_desc.release(); d_perm.release(); tickets.release(); simd_arrivals.release(); sort_ws.release();
         enc_gs.release(); dec_gs.release();
         if (staged) (void)hipEventDestroy(staged);
         staged = nullptr;
@@ -615,6 +616,60 @@ int32_t cramgpu_rans_encode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_
     if (int rc = enter(c, s)) return rc;
     CallScope scope{c, s};
     return rans_run(c, c->res, true, d_in, d_out, blocks, n, d_out_len, d_out_pos, s);
+}
+
+int32_t cramgpu_rans_encode_series_dev(cramgpu_ctx* c, const uint8_t* d_base, int64_t in_shift, const int64_t* d_series_off,
+                                       const int32_t* d_series_len, const int32_t* d_w_status, int32_t n_cont,
+                                       const int32_t* ids, const int32_t* orders, int32_t n_ids, uint8_t* d_out,
+                                       int64_t out_cap, cramgpu_block* d_blocks, int32_t* d_out_len, int64_t* d_out_pos,
+                                       int32_t* d_status, void* stream) {
+    if (!c || n_cont < 0 || n_ids < 0 || n_ids > CRAMGPU_N_SERIES || (int64_t)n_cont * n_ids > INT32_MAX ||
+        (n_cont > 0 && n_ids > 0 && (!d_base || !d_series_off || !d_series_len || !ids || !orders || !d_out || !d_blocks ||
+                                     !d_out_len || !d_out_pos || !d_status)))
+        return fail(CRAMGPU_E_ARG, "cramgpu_rans_encode_series_dev: bad argument");
+    if ((in_shift % CRAMGPU_ARENA_ALIGN) != 0) return fail(CRAMGPU_E_ARG, "cramgpu_rans_encode_series_dev: in_shift must be a multiple of CRAMGPU_ARENA_ALIGN");
+    SeriesPick sel{};
+    sel.n_ids = n_ids;
+    for (int32_t k = 0; k < n_ids; k++) {
+        if (ids[k] < 0 || ids[k] >= CRAMGPU_N_SERIES) return fail(CRAMGPU_E_ARG, "cramgpu_rans_encode_series_dev: unknown series id");
+        if (orders[k] != 0 && orders[k] != 1) return fail(CRAMGPU_E_ORDER, "Unknown rANS order");
+        sel.ids[k] = ids[k];
+        sel.orders[k] = orders[k];
+    }
+    const int32_t n = n_cont * n_ids;
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t s = pick(c, stream);
+    if (int rc = enter(c, s)) return rc;
+    CallScope scope{c, s};
+    HIPCHK(hipSetDevice(c->device));
+    LaunchRes& r = c->res;
+    const int groups = std::min(n, c->n_waves_enc);
+    const size_t ws_bytes = lpt_sort_bytes(n);
+    HIPCHK(r.d_perm.reserve(n));
+    HIPCHK(r.sort_ws.reserve(ws_bytes));
+    HIPCHK(r.tickets.reserve(kTicketSlots));
+    HIPCHK(r.enc_gs.reserve((size_t)((groups + 3) & ~3) * ENC_GSCRATCH_BYTES));
+    // the table, its longest-first order, the encoder: all in stream order, nothing comes back to the host in between
+    HIPCHK(launch_series_blocks(d_series_off, d_series_len, n_cont, sel, in_shift, out_cap, d_w_status, d_blocks, d_status, s));
+    HIPCHK(launch_lpt_sort(d_blocks, n, r.d_perm.p, r.sort_ws.p, ws_bytes, s));
+    uint32_t* ticket = r.tickets.p + 2 * (r.ticket_next++ % (kTicketSlots / 2));
+    HIPCHK(hipMemsetAsync(ticket, 0, 2 * sizeof(uint32_t), s));
+    RansArgs a{};
+    a.in = d_base;
+    a.out = d_out;
+    a.desc = d_blocks;
+    a.perm = r.d_perm.p;
+    a.n_blocks = n;
+    a.out_len = d_out_len;
+    a.out_pos = d_out_pos;
+    a.ticket = ticket;
+    a.rcp_tab = c->rcp_tab.p;
+    a.tab_bytes = c->tab_bytes;
+    a.prof = nullptr;
+    a.gscratch = r.enc_gs.p;
+    HIPCHK(launch_rans_encode(a, groups, c->enc_lds, s));
+    return 0;
 }
 
 int32_t cramgpu_rans_encode_static(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks,

@@ -53,6 +53,17 @@ hipError_t launch_rans_encode(const RansArgs& a, int n_groups, size_t lds_bytes,
 hipError_t launch_rans_decode(const RansArgs& a, int n_waves, size_t lds_bytes, hipStream_t s);
 hipError_t launch_rcp_init(uint32_t* d_rcp_tab, hipStream_t s);
 hipError_t launch_lpt_perm(const cramgpu_block* d_desc, int32_t n, int32_t* d_perm, hipStream_t s);  // n <= 4096
+// cramgpu_rans_encode_series_dev: the block table and its longest-first order made on the device (gather.hip)
+struct SeriesPick {
+    int32_t n_ids;
+    int32_t ids[CRAMGPU_N_SERIES];     // content ids of the series to code, in block order
+    int32_t orders[CRAMGPU_N_SERIES];  // their rANS orders
+};
+hipError_t launch_series_blocks(const int64_t* d_series_off, const int32_t* d_series_len, int32_t n_cont, const SeriesPick& pick,
+                                int64_t in_shift, int64_t out_cap, const int32_t* d_w_status, cramgpu_block* d_blocks,
+                                int32_t* d_status, hipStream_t s);
+size_t lpt_sort_bytes(int32_t n);
+hipError_t launch_lpt_sort(const cramgpu_block* d_desc, int32_t n, int32_t* d_perm, void* ws, size_t ws_bytes, hipStream_t s);
 size_t rans_encode_fixed_lds();
 size_t rans_decode_fixed_lds();
 hipError_t launch_gather(const uint8_t* src, const int64_t* pos, const int32_t* len, int32_t n, int32_t align,

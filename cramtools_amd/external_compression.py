@@ -137,6 +137,24 @@ class Engine:
         _lib.check(_lib.lib().cramgpu_rans_encode_dev(self._h, p_in, d_out.data_ptr(), pb, n,
                                                       d_out_len.data_ptr(), d_out_pos.data_ptr(), s))
 
+    def encode_series_dev(self, base, in_shift, d_series_off, d_series_len, d_w_status, n_cont, ids, orders, d_out, d_blocks,
+                          d_out_len, d_out_pos, d_status, stream=None):
+        """The encoder straight behind the data-series writer (cramgpu_rans_encode_series_dev): block c * len(ids) + k is
+        series ids[k] of container c; the block table (d_blocks, a DEVICE uint8 tensor of 32 bytes per block) and its
+        longest-first order are made on the device, nothing comes back to the host before the launch."""
+        import numpy as np
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        ids = np.ascontiguousarray(ids, np.int32)
+        orders = np.ascontiguousarray(orders, np.int32)
+        assert ids.size == orders.size and d_blocks.numel() >= 32 * n_cont * ids.size
+        p_base = base if isinstance(base, int) else base.data_ptr()
+        _lib.check(_lib.lib().cramgpu_rans_encode_series_dev(
+            self._h, p_base, int(in_shift), d_series_off.data_ptr(), d_series_len.data_ptr(),
+            d_w_status.data_ptr() if d_w_status is not None else None, int(n_cont), ids.ctypes.data, orders.ctypes.data,
+            int(ids.size), d_out.data_ptr(), int(d_out.numel()), d_blocks.data_ptr(), d_out_len.data_ptr(),
+            d_out_pos.data_ptr(), d_status.data_ptr(), s))
+
     def decode_dev(self, d_in, d_out, blocks, n, d_out_len, stream=None):
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream

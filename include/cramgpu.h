@@ -400,6 +400,27 @@ int32_t cramgpu_write_series_dev(cramgpu_ctx* ctx, const cramgpu_reads* reads, c
                                  const cramgpu_features* feats, uint8_t* d_arena, int64_t arena_cap, int64_t* d_series_off,
                                  int32_t* d_series_len, int32_t* d_status, void* stream);
 
+/* The rANS encoder straight behind cramgpu_write_series_dev, with no host round trip between the two: the per-container
+ * compress loop of ContainerFactory#buildSlice L198-201 over the series ExternalCompressor codes with rANS
+ * (CompressionHeaderFactory#build L82-124), for all containers of the batch in one launch.  cramgpu_rans_encode_dev wants
+ * its block table on the host, which costs a device-to-host copy of the stream lengths, the table's making and its upload
+ * while the GPU idles (about 1 ms of a 13 ms step at 1000 containers); here the table is made on the device:
+ *   block b = c * n_ids + k  is series ids[k] (content id) of container c, coded with order orders[k] (0 or 1);
+ *   its input is d_base[in_shift + d_series_off[c * CRAMGPU_N_SERIES + ids[k]] .. + d_series_len[...]) — in_shift rebases
+ *   the writer's offsets (relative to its arena; streams aliased into the caller's quality array lie outside it) on a
+ *   base address below all of them; in_shift and the offsets are multiples of CRAMGPU_ARENA_ALIGN;
+ *   its output slot has cramgpu_rans_bound(length) bytes, the slots follow one another on 16-byte boundaries in d_out.
+ * d_blocks[n_cont * n_ids] (DEVICE, written by the call) receives the table, for the host to read afterwards together
+ * with d_out_len / d_out_pos (as cramgpu_rans_encode_dev fills them).  d_status[0] = 0; or the writer's status when
+ * d_w_status (may be NULL) points at a non-zero one; or CRAMGPU_E_INSUFFICIENT when the slots need more than out_cap
+ * bytes — then every block is left empty (d_out_len[b] = 0).  The longest-first order of the launch is a radix sort on
+ * the device.  Stream-ordered, does not synchronise. */
+int32_t cramgpu_rans_encode_series_dev(cramgpu_ctx* ctx, const uint8_t* d_base, int64_t in_shift, const int64_t* d_series_off,
+                                       const int32_t* d_series_len, const int32_t* d_w_status, int32_t n_cont,
+                                       const int32_t* ids, const int32_t* orders, int32_t n_ids, uint8_t* d_out,
+                                       int64_t out_cap, cramgpu_block* d_blocks, int32_t* d_out_len, int64_t* d_out_pos,
+                                       int32_t* d_status, void* stream);
+
 /* What the reader produces besides cramgpu_record_cols and cramgpu_features (device arrays). */
 typedef struct {
     int32_t* read_len;   /* [n_reads] RL */

@@ -151,6 +151,70 @@ def test_writer_feeds_the_encoder(orc):
         for i, (k, o) in enumerate(ids):
             got = d_out[int(d_pos[i]):int(d_pos[i]) + int(d_len[i])].cpu().numpy().tobytes()
             assert got == orc.rans(want[k], o), k
+        # cramgpu_rans_encode_series_dev: the same blocks, their table made on the device behind the writer (both writers:
+        # in_shift rebases the aliased QS stream), slots of cramgpu_rans_bound bytes one after the other
+        for wr, shift_base in ((w, w.arena.data_ptr()), (w2, base)):
+            d_blk = torch.zeros(32 * len(ids), dtype=torch.uint8, device=DEV)
+            d_st = torch.full((1,), 77, dtype=torch.int32, device=DEV)
+            d_out.zero_()
+            eng.encode_series_dev(shift_base, wr.arena.data_ptr() - shift_base, wr.off, wr.len, wr.status, 1,
+                                  [k for k, _ in ids], [o for _, o in ids], d_out, d_blk, d_len, d_pos, d_st)
+            assert int(d_st.item()) == 0
+            tab = d_blk.cpu().numpy().view(_lib.BLOCK_DTYPE)
+            o_w, l_w = wr.lengths()
+            at = 0
+            for i, (k, o) in enumerate(ids):
+                assert (int(tab["in_off"][i]), int(tab["in_len"][i]), int(tab["order"][i])) == \
+                    (int(o_w[0, k]) + wr.arena.data_ptr() - shift_base, int(l_w[0, k]), o)
+                assert int(tab["out_cap"][i]) == _lib.lib().cramgpu_rans_bound(int(l_w[0, k])) and int(tab["out_off"][i]) == at
+                at += (int(tab["out_cap"][i]) + 15) // 16 * 16
+                got = d_out[int(d_pos[i]):int(d_pos[i]) + int(d_len[i])].cpu().numpy().tobytes()
+                assert got == orc.rans(want[k], o), k
+        # slots that do not fit the output arena: a status, and every block left empty
+        d_st.fill_(77)
+        d_len.fill_(5)
+        eng.encode_series_dev(w.arena.data_ptr(), 0, w.off, w.len, w.status, 1, [k for k, _ in ids], [o for _, o in ids],
+                              d_out[:at - 16], d_blk, d_len, d_pos, d_st)
+        assert int(d_st.item()) == _lib.E_INSUFFICIENT and bool((d_len == 0).all())
+    finally:
+        eng.close()
+
+
+def test_encoder_behind_the_writer_many_blocks(orc):
+    """cramgpu_rans_encode_series_dev over more blocks than the 4096 an LDS sort holds (the longest-first order is a radix
+    sort on the device): 600 containers x 8 series of random short streams, every stream against the oracle."""
+    import torch
+    from cramtools_amd import external_compression as xc, _lib
+    rng = np.random.default_rng(11)
+    n_cont, ns = 600, _lib.N_SERIES
+    ids = [4, 1, 6, 0, 21, 14, 9, 25]
+    orders = [1, 0, 1, 1, 1, 1, 1, 0]
+    ln = np.zeros((n_cont, ns), np.int32)
+    ln[:, ids] = rng.integers(0, 400, (n_cont, len(ids)))
+    ln[rng.integers(0, n_cont, 40), rng.choice(ids, 40)] = 0        # empty streams among them
+    ln[5, 4], ln[77, 6] = 70000, 30000                               # and two long ones
+    slot = (ln.astype(np.int64) + 15) // 16 * 16
+    off = (np.cumsum(slot.reshape(-1)) - slot.reshape(-1)).reshape(n_cont, ns)
+    arena = rng.integers(0, 7, int(slot.sum()) + 16).astype(np.uint8) * 9
+    eng = xc.Engine(0)
+    try:
+        d_arena = torch.as_tensor(arena).to(DEV)
+        d_off, d_ln = torch.as_tensor(off.reshape(-1)).to(DEV), torch.as_tensor(ln.reshape(-1)).to(DEV)
+        n = n_cont * len(ids)
+        caps = np.array([_lib.lib().cramgpu_rans_bound(int(x)) for x in ln[:, ids].reshape(-1)], np.int64)
+        d_out = torch.zeros(int(((caps + 15) // 16 * 16).sum()) + 16, dtype=torch.uint8, device=DEV)
+        d_blk = torch.zeros(32 * n, dtype=torch.uint8, device=DEV)
+        d_len, d_pos = torch.zeros(n, dtype=torch.int32, device=DEV), torch.zeros(n, dtype=torch.int64, device=DEV)
+        d_st = torch.full((1,), 77, dtype=torch.int32, device=DEV)
+        for _ in range(2):  # twice: the workspaces of the first call are reused
+            eng.encode_series_dev(d_arena, 0, d_off, d_ln, None, n_cont, ids, orders, d_out, d_blk, d_len, d_pos, d_st)
+        assert int(d_st.item()) == 0
+        lens, pos, out = d_len.cpu().numpy(), d_pos.cpu().numpy(), d_out.cpu().numpy()
+        for c in range(n_cont):
+            for k, (sid, o) in enumerate(zip(ids, orders)):
+                b = c * len(ids) + k
+                raw = arena[off[c, sid]:off[c, sid] + ln[c, sid]].tobytes()
+                assert out[pos[b]:pos[b] + lens[b]].tobytes() == orc.rans(raw, o), (c, sid)
     finally:
         eng.close()
 
