@@ -575,24 +575,44 @@ __global__ __launch_bounds__(64) void series_parse_kernel(RArgs A) {
             const unsigned long long V = __ballot(valid);
             const unsigned long long G2 = __ballot(valid && b[0] >= 0x80u), G3 = __ballot(valid && b[0] >= 0xC0u),
                                      G4 = __ballot(valid && b[0] >= 0xE0u), G5 = __ballot(valid && b[0] >= 0xF0u);
-            // the true starts of the chunk: a run of equal-length values per turn
+            const int lead = __clz((int)~(b[0] << 24));
+            const int m = (lead < 4 ? lead : 4) + 1;
+            // the true starts of the chunk.  First a run of equal-length values (the run's starts are a periodic pattern:
+            // one turn covers the whole chunk of a same-width stream) ...
             unsigned long long S = 0;
             int32_t pp = e;
-            while (pp < 64 && ((V >> pp) & 1ull)) {
-                const int m = 1 + (int)((G2 >> pp) & 1ull) + (int)((G3 >> pp) & 1ull) + (int)((G4 >> pp) & 1ull) +
-                              (int)((G5 >> pp) & 1ull);
-                const unsigned long long Lm = m == 1 ? V & ~G2 : m == 2 ? G2 & ~G3 : m == 3 ? G3 & ~G4 : m == 4 ? G4 & ~G5 : G5;
-                const unsigned long long pat = itf8_pattern(m);
+            if (pp < 64 && ((V >> pp) & 1ull)) {
+                const int mr = 1 + (int)((G2 >> pp) & 1ull) + (int)((G3 >> pp) & 1ull) + (int)((G4 >> pp) & 1ull) +
+                               (int)((G5 >> pp) & 1ull);
+                const unsigned long long Lm = mr == 1 ? V & ~G2 : mr == 2 ? G2 & ~G3 : mr == 3 ? G3 & ~G4 : mr == 4 ? G4 & ~G5 : G5;
+                const unsigned long long pat = itf8_pattern(mr);
                 const unsigned long long brk = ~(Lm >> pp) & pat;  // first pattern position that does not open such a value
                 const int t = brk ? __ffsll((long long)brk) - 1 : 64;
                 const unsigned long long take = pat & (t >= 64 ? ~0ull : ((1ull << t) - 1ull));
                 S |= take << pp;
-                pp += m * __popcll(take);
+                pp += mr * __popcll(take);
+            }
+            // ... and where widths mix (template sizes, mate positions: a turn per value cost ~4000 cycles a chunk), no walk
+            // at all: "bytes of the current value still to come" behind a byte is a function of the same count in front
+            // of it (0 -> width - 1, k -> k - 1), five 3-bit entries in a word; a prefix scan composes the functions over
+            // the lanes, and a byte opens a value where the count in front of it is 0.
+            if (pp < 64 && ((V >> pp) & 1ull)) {
+                uint32_t P = (uint32_t)(m - 1) | 0x3440u;  // f(0) = m - 1, f(1..4) = 0..3
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t T = __shfl_up(P, d);  // the lanes l - 2d + 1 .. l - d: applied first
+                    uint32_t r = 0;
+#pragma unroll
+                    for (int q5 = 0; q5 < 5; q5++) r |= ((P >> (3u * ((T >> (3 * q5)) & 7u))) & 7u) << (3 * q5);
+                    P = l >= d ? r : P;
+                }
+                const uint32_t prev = __shfl_up(P, 1);
+                const uint32_t before = l == 0 ? (uint32_t)e : (prev >> (3 * e)) & 7u;
+                S = __ballot(valid && before == 0u);
+                pp = 64 + (int32_t)((__shfl(P, 63) >> (3 * e)) & 7u);
             }
             e = pp >= 64 ? pp - 64 : 0;
             const bool start = (S >> l) & 1ull;
-            const int lead = __clz((int)~(b[0] << 24));
-            const int m = (lead < 4 ? lead : 4) + 1;
             if (start && q + m > n) bad = true;  // the stream ends inside a value
             const unsigned long long W = ((unsigned long long)b[0] << 32) | (b[1] << 24) | (b[2] << 16) | (b[3] << 8) | b[4];
             const uint32_t v4 = (uint32_t)(W >> (8 * (5 - m))) & ((1u << (m == 5 ? 0 : 7 * m)) - 1u);
