@@ -209,15 +209,20 @@ def test_gunzip_test_bodies(hostsim, monkeypatch):
     """tests/test_gunzip_gpu.py on the host build of csrc/inflate.hip."""
     import test_gunzip_gpu as t
     monkeypatch.setattr(t, "DEV", "cpu")
-    t.test_gunzip_matches_zlib()
+    # the corpus through the lane-per-stream kernel; the wave-per-stream kernel (a barrier of 64 host threads per match
+    # here) on its own small streams
+    monkeypatch.setenv("CRAMGPU_GUNZIP_LANES", "2")
+    t.test_gunzip_matches_zlib("2", monkeypatch)
     t.test_bgzf_blocks()
-    t.test_gunzip_failures()
+    t.test_gunzip_failures("2", monkeypatch)
+    t.test_wave_kernel_small_streams(monkeypatch)
 
 
 def test_gzip_test_bodies(hostsim, monkeypatch):
     """tests/test_gzip_gpu.py on the host build of csrc/deflate.hip."""
     import test_gzip_gpu as t
     monkeypatch.setattr(t, "DEV", "cpu")
+    monkeypatch.setenv("CRAMGPU_GUNZIP_LANES", "2")  # the members are inflated again by the device kernel
     # (test_members_inflate_to_the_input: the same inputs run under the sanitizers in tests/test_kernels_hostsim.py)
     t.test_bgzf_image()
     t.test_long_series_as_several_members()

@@ -54,8 +54,14 @@ def _corpus(rng):
     return [b"", b"a", b"abc" * 5, acgt, quals, noise, runs, names, acgt[:257], bytes(1000), noise[:5], every_len, periods]
 
 
-def test_gunzip_matches_zlib():
+# both kernels: a wave per stream ("64": what a launch of few streams gets) and a lane per stream ("2": a launch of many)
+KERNELS = ("64", "2")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_gunzip_matches_zlib(kernel, monkeypatch):
     from cramtools_amd import external_compression as xc
+    monkeypatch.setenv("CRAMGPU_GUNZIP_LANES", kernel)
     rng = np.random.default_rng(17)
     corpus = _corpus(rng)
     streams, want = [], []
@@ -87,6 +93,40 @@ def test_gunzip_matches_zlib():
         eng.close()
 
 
+def test_wave_kernel_small_streams(monkeypatch):
+    """The wave-per-stream kernel on streams small enough for the thread-per-lane host build (tests/test_glue_hostsim.py):
+    stored, fixed and dynamic blocks, overlapping runs, matches longer than 64 bytes, two members in a row, an empty one."""
+    from cramtools_amd import external_compression as xc
+    monkeypatch.setenv("CRAMGPU_GUNZIP_LANES", "64")
+    rng = np.random.default_rng(5)
+    text = b"".join(b"read.%d/%d\t" % (i, i % 7) for i in range(60))
+    seed = rng.integers(0, 256, 200).astype(np.uint8).tobytes()
+    datas = [b"", b"a", b"abcabcabcabcabcabcabcabc", text, seed + seed[:150] + seed[20:190], bytes(700) + b"\1\2" * 300,
+             seed[:40]]
+    streams, want = [], []
+    for i, d in enumerate(datas):
+        for level in (0, 1, 6):
+            streams.append(_member(d, level))
+            want.append(d)
+    streams.append(_member(text, 6, zlib.Z_FIXED))
+    want.append(text)
+    streams.append(_member(text, 6) + _member(seed, 1) + b"\0\0\0")  # two members and padding behind them
+    want.append(text + seed)
+    eng = xc.Engine(0)
+    try:
+        got = eng.gunzip_many(streams, [len(w) for w in want], device=DEV)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g == w, i
+        bad = bytearray(_member(text, 6))
+        bad[-6] ^= 1  # CRC-32
+        with pytest.raises(Exception):
+            eng.gunzip_many([bytes(bad)], [len(text)], device=DEV)
+        with pytest.raises(Exception):
+            eng.gunzip_many([_member(text, 6)[:-20]], [len(text)], device=DEV)  # truncated
+    finally:
+        eng.close()
+
+
 def test_bgzf_blocks():
     """A BAM-like BGZF image: indexed on the host from the BC subfields, every block inflated in one call."""
     import torch
@@ -113,7 +153,9 @@ def test_bgzf_blocks():
         eng.close()
 
 
-def test_gunzip_failures():
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_gunzip_failures(kernel, monkeypatch):
+    monkeypatch.setenv("CRAMGPU_GUNZIP_LANES", kernel)
     import torch
     from cramtools_amd import _lib, external_compression as xc
     rng = np.random.default_rng(29)
