@@ -860,12 +860,13 @@ hipError_t launch_gunzip(const uint8_t* in, uint8_t* out, const cramgpu_block* d
     const char* env = getenv("CRAMGPU_GUNZIP_LANES");
     int forced = env ? atoi(env) : 0;
     if (forced != 2 && forced != 4 && forced != 8 && forced != 16 && forced != 64) {
-        int n_cu = 256;
-#ifndef HIP_SIM
-        int dev = 0;
+#ifdef HIP_SIM
+        forced = 2;  // the thread-per-lane host build pays a barrier of 64 threads per match in the wave kernel: only on request
+#else
+        int dev = 0, n_cu = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-#endif
         forced = n <= 64 * n_cu ? 64 : 2;
+#endif
     }
     if (forced == 64) {
         hipLaunchKernelGGL(gunzip_wave_kernel, dim3((unsigned)n), dim3(64), 0, s, in, out, d_desc, n, out_len);

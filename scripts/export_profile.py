@@ -4,7 +4,7 @@ summaries kept under profiles/ (per round)."""
 import collections, csv, os, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-out = os.path.join(ROOT, "profiles")
+out = os.path.join(ROOT, sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")  # on the GPU box: gpurun_out/summary
 os.makedirs(out, exist_ok=True)
 db = sqlite3.connect(os.path.join(ROOT, "gpurun_out/prof/bench_results.db"))
 cur = db.cursor()

@@ -2,12 +2,12 @@
 # The round's evidence in one call (every step under its own time limit, nothing runs after a failure):
 #   1. full GPU suite   2. bench line   3. rocprofv3 --kernel-trace --stats of the bench command
 #   4. one --pmc pass per HBM counter (FETCH_SIZE, WRITE_SIZE do not fit one pass)   5. one SQ-counter pass of the rANS kernels
-# Afterwards, here: python scripts/export_profile.py rNN  copies the summaries into profiles/.
+#   6. summary: the small per-kernel summaries (gpurun_out/summary/) — copy them into profiles/ here afterwards
 # Usage: bash scripts/gr.sh 'bash scripts/gpu_round.sh [tests|bench|trace|pmc|sq ...]'   (default: all five)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
-STEPS=${@:-tests bench trace pmc sq}
+STEPS=${@:-tests bench trace pmc sq summary}
 KERNELS="rans_encode|rans_decode|extract_|gather_copy|restore_|series_|gunzip|gzip|bam_|cigar_|mates_|mate_|content_crc|slice_md5"
 for step in $STEPS; do
   case $step in
@@ -47,6 +47,11 @@ for k, d in agg.items():
         print("  %-22s dispatches %d mean %.4g" % (c, len(v), sum(v) / len(v)))
 PY
       cat $R/gpurun_out/sq_counters.txt ;;
+    summary)  # the small summaries of the trace and PMC passes (what profiles/ keeps); the trace database stays on the box
+      cd $R
+      python3 scripts/export_profile.py ${ROUND_TAG:-r03} gpurun_out/summary > /dev/null || { echo "summary failed"; exit 1; }
+      rm -rf gpurun_out/prof
+      ls gpurun_out/summary ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
