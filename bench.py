@@ -283,6 +283,11 @@ class Step:
         self.gz_piece = 8192
         self.gz_desc = None
         self.side = torch.cuda.Stream(device=dev)
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.ev_w = torch.cuda.Event()
+        self.pin_off = torch.zeros(n_cont * _lib.N_SERIES, dtype=torch.int64).pin_memory()
+        self.pin_len = torch.zeros(n_cont * _lib.N_SERIES, dtype=torch.int32).pin_memory()
+        self.pin_st = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.ev_full = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         self.full_ms = []
         from cramtools_amd import bam as bam_mod
@@ -331,16 +336,25 @@ class Step:
         self.fac.matrices_and_codes(reads, self.feats, self.hist, self.mats)
         self.ser.set_mate_info(cols, self.cont_first, reads.aln_start, self.aln_end, self.names, self.name_off, self.name_len)
         self.writer.write(reads, cols, self.feats)
-        off, ln = self.writer.lengths()
-        blk = self.blk
-        blk["in_off"], blk["in_len"] = off[:, self.ids].reshape(-1), ln[:, self.ids].reshape(-1)
-        cap = (1.05 * blk["in_len"].astype(np.float64) + 257.0 * 257.0 * 3.0 + 4.0).astype(np.int32)
-        blk["out_cap"] = cap
-        slot = (cap.astype(np.int64) + 15) // 16 * 16
-        blk["out_off"] = np.cumsum(slot) - slot
+        self.ev_w.record(main)
+        # K1 straight behind W (block table and launch order made on the device: cramgpu_rans_encode_series_dev), the
+        # gather behind it.  The stream lengths go to the host on a stream of their own that waits for W only, and the
+        # host lays out the gzip members while the encoder runs.
         p_arena = self.writer.arena.data_ptr()
         base = min(p_arena, reads.quals.data_ptr()) & ~15
-        blk["in_off"] += p_arena - base
+        self.eng.encode_series_dev(base, p_arena - base, self.writer.off, self.writer.len, self.writer.status, w["n_cont"],
+                                   self.ids, self.orders, self.d_out, self.d_blk, self.d_len, self.d_pos, self.d_blk_status)
+        self.eng.gather_dev(self.d_out, self.d_pos, self.d_len, w["n_blocks"], w["max_cap"], self.d_pack, self.d_pack_off)
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.ev_w)
+            self.pin_off.copy_(self.writer.off, non_blocking=True)
+            self.pin_len.copy_(self.writer.len, non_blocking=True)
+            self.pin_st.copy_(self.writer.status, non_blocking=True)
+        self.copy_stream.synchronize()
+        if int(self.pin_st[0]) != 0:
+            raise _lib.CramGpuError(int(self.pin_st[0]), "data-series writer")
+        off = self.pin_off.numpy().reshape(w["n_cont"], _lib.N_SERIES)
+        ln = self.pin_len.numpy().reshape(w["n_cont"], _lib.N_SERIES)
         gd, gz_bytes = self._gzip_plan(off, ln)
         if self.gz_desc is None:  # first (warm-up) call: buffers with headroom for later calls
             self.gz_desc = torch.zeros(int(gd.size * 1.25) + 1024, BLOCK_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
@@ -351,11 +365,9 @@ class Step:
         self.gz_pin[:gd.size] = torch.from_numpy(gd.view(np.uint8).reshape(gd.size, -1))
         self.gz_desc[:gd.size].copy_(self.gz_pin[:gd.size], non_blocking=True)
         self.n_gz, self.gz_plan = int(gd.size), gd
-        # Z before K1 on the same stream: the encoder's resident workgroups hold the whole LDS of every CU, a gzip wave
+        # Z behind K1 on the same stream: the encoder's resident workgroups hold the whole LDS of every CU, a gzip wave
         # (9.5 KiB of tables) finds no room beside them and would only start as they retire
         self.eng.gzip_dev(self.writer.arena, self.gz_out, self.gz_desc, self.n_gz, self.gz_len)
-        self.eng.encode_dev(base, self.d_out, blk, w["n_blocks"], self.d_len, self.d_pos)
-        self.eng.gather_dev(self.d_out, self.d_pos, self.d_len, w["n_blocks"], w["max_cap"], self.d_pack, self.d_pack_off)
         main.wait_stream(self.side)
         if timed:
             self.ev_full[1].record()
