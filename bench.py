@@ -459,7 +459,10 @@ class DecodeStep:
             self.rflags = reads.rflags | 16  # CRAMGPU_RF_FORCE_QS: lossless records carry CF_FORCE_PRESERVE_QS
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         self.k2_ms, self.ms, self.bam_ms, self.gz_ms = [], [], [], []
-        self.side = torch.cuda.Stream(device=dev) if str(dev).startswith("cuda") else None
+        # G's stream has the lowest priority the device offers: K2 and G become ready at the same moment, and when G's
+        # 10 000 workgroups reach the CUs first they keep the decoder's resident waves out for the length of G's streams
+        # (K2 50 ms instead of 26: seen in two of eight launches of a profiled run)
+        self.side = torch.cuda.Stream(device=dev, priority=10) if str(dev).startswith("cuda") else None
 
     def run(self, timed=True):
         w, L, reads = self.w, _lib.lib(), self.w["reads"]
@@ -481,6 +484,9 @@ class DecodeStep:
             if side is None:  # host build of the kernels (tests/test_glue_hostsim.py)
                 self.eng.gunzip_dev(self.d_gz, self.d_gz_raw, self.d_gz_desc, self.n_gz, self.d_gz_len, stream=0)
             else:
+                # ... and not before K2's kernel is the next thing in its stream (its block table is on the device): on a
+                # backlogged GPU G's wait ends the moment K2's staging copies begin, and G would reach the CUs first
+                _lib.check(L.cramgpu_stream_wait_staged(self.eng.handle, side.cuda_stream))
                 with torch.cuda.stream(side):
                     self.eng.gunzip_dev(self.d_gz, self.d_gz_raw, self.d_gz_desc, self.n_gz, self.d_gz_len)
                     if timed:

@@ -153,6 +153,7 @@ SYMBOLS = {
     "cramgpu_rans_raw_size": (I32, [P, I32]),
     "cramgpu_rans_encode_dev": (I32, [P, P, P, P, I32, P, P, P]),
     "cramgpu_rans_encode_static": (I32, [P, P, P, P, I32, P, P, P]),
+    "cramgpu_stream_wait_staged": (I32, [P, P]),
     "cramgpu_rans_encode_series_dev": (I32, [P, P, I64, P, P, P, I32, P, P, I32, P, I64, P, P, P, P, P]),
     "cramgpu_rans_decode_dev": (I32, [P, P, P, P, I32, P, P]),
     "cramgpu_gather_dev": (I32, [P, P, P, P, I32, I32, I32, P, I64, P, P]),

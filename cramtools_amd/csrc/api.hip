@@ -129,6 +129,7 @@ struct LaunchRes {
     DevBuf<uint32_t> simd_arrivals;  // decoder: waves of the launch per SIMD (rans_dec.hip, first_wave_on_simd)
     DevBuf<uint8_t> sort_ws;         // cramgpu_rans_encode_series_dev: workspace of the longest-first sort on the device
     uint32_t ticket_next = 0;
+    uint32_t launch_no = 0;          // decoder launches so far (the arrival table's stamp)
     DevBuf<uint8_t> enc_gs, dec_gs;
     void release() {
         h_desc.release(); h_perm.release(); d_desc.release(); d_perm.release(); tickets.release(); simd_arrivals.release(); sort_ws.release();
@@ -328,6 +329,17 @@ int stage_blocks(LaunchRes& r, const cramgpu_block* blocks, int32_t n, hipStream
     return 0;
 }
 
+// The work-queue word(s) of a launch: 8 bytes of a ring that is cleared when it is made; every launch clears its slot
+// behind itself (stream order), so no fill runs in front of a kernel.
+int next_ticket(LaunchRes& r, hipStream_t s, uint32_t** out) {
+    if (!r.tickets.p) {
+        HIPCHK(r.tickets.reserve(kTicketSlots));
+        HIPCHK(hipMemsetAsync(r.tickets.p, 0, r.tickets.cap * sizeof(uint32_t), s));
+    }
+    *out = r.tickets.p + 2 * (r.ticket_next++ % (kTicketSlots / 2));
+    return 0;
+}
+
 int rans_run(cramgpu_ctx* c, LaunchRes& r, bool encode, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,
              int32_t n, int32_t* d_out_len, int64_t* d_out_pos, hipStream_t s) {
     if (n == 0) return 0;
@@ -352,13 +364,12 @@ int rans_run(cramgpu_ctx* c, LaunchRes& r, bool encode, const uint8_t* d_in, uin
         const int64_t need = (total + longest - 1) / longest;
         groups = (int)std::min<int64_t>(groups, need + need / 8 + 8);
     }
-    HIPCHK(r.tickets.reserve(kTicketSlots));
     if (encode)
         HIPCHK(r.enc_gs.reserve((size_t)((groups + 3) & ~3) * ENC_GSCRATCH_BYTES));  // four slots to a workgroup
     else
         HIPCHK(r.dec_gs.reserve((size_t)groups * DEC_GSCRATCH_BYTES));
-    uint32_t* ticket = r.tickets.p + 2 * (r.ticket_next++ % (kTicketSlots / 2));  // 8 bytes a launch (the decoder's two ends)
-    HIPCHK(hipMemsetAsync(ticket, 0, 2 * sizeof(uint32_t), s));
+    uint32_t* ticket = nullptr;
+    if (int trc = next_ticket(r, s, &ticket)) return trc;
     RansArgs a{};
     a.in = d_in;
     a.out = d_out;
@@ -373,9 +384,15 @@ int rans_run(cramgpu_ctx* c, LaunchRes& r, bool encode, const uint8_t* d_in, uin
     a.prof = nullptr;
     a.simd_arrivals = nullptr;
     if (!encode && c->dec_roles) {
-        HIPCHK(r.simd_arrivals.reserve(DEC_SIMD_KEYS));
-        HIPCHK(hipMemsetAsync(r.simd_arrivals.p, 0, DEC_SIMD_KEYS * sizeof(uint32_t), s));
+        // the arrival table holds the number of the last launch whose wave came by (atomicMax): cleared once, when it is
+        // made — no fill in front of the kernel, which would let a kernel launched beside it on another stream (the gunzip
+        // of the same batch) reach the CUs first and keep the decoder's resident waves out for the length of its streams
+        if (!r.simd_arrivals.p) {
+            HIPCHK(r.simd_arrivals.reserve(DEC_SIMD_KEYS));
+            HIPCHK(hipMemsetAsync(r.simd_arrivals.p, 0, r.simd_arrivals.cap * sizeof(uint32_t), s));
+        }
         a.simd_arrivals = r.simd_arrivals.p;
+        a.launch_no = ++r.launch_no;
     }
     if (encode && c->prof_on) {  // profiling aid: per-block cycle counters, printed after a synchronising copy
         HIPCHK(c->d_prof.reserve((size_t)n * 8));
@@ -432,6 +449,7 @@ int rans_run(cramgpu_ctx* c, LaunchRes& r, bool encode, const uint8_t* d_in, uin
         a.gscratch = r.dec_gs.p;
         HIPCHK(launch_rans_decode(a, groups, c->dec_lds, s));
     }
+    HIPCHK(hipMemsetAsync(ticket, 0, 2 * sizeof(uint32_t), s));  // behind the launch: the slot is clean when its turn comes again
     return 0;
 }
 
@@ -618,6 +636,16 @@ int32_t cramgpu_rans_encode_dev(cramgpu_ctx* c, const uint8_t* d_in, uint8_t* d_
     return rans_run(c, c->res, true, d_in, d_out, blocks, n, d_out_len, d_out_pos, s);
 }
 
+int32_t cramgpu_stream_wait_staged(cramgpu_ctx* c, void* stream) {
+    if (!c) return fail(CRAMGPU_E_ARG, "cramgpu_stream_wait_staged: bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->res.staged && c->res.staged_pending) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->res.staged, 0));
+    }
+    return 0;
+}
+
 int32_t cramgpu_rans_encode_series_dev(cramgpu_ctx* c, const uint8_t* d_base, int64_t in_shift, const int64_t* d_series_off,
                                        const int32_t* d_series_len, const int32_t* d_w_status, int32_t n_cont,
                                        const int32_t* ids, const int32_t* orders, int32_t n_ids, uint8_t* d_out,
@@ -648,13 +676,12 @@ int32_t cramgpu_rans_encode_series_dev(cramgpu_ctx* c, const uint8_t* d_base, in
     const size_t ws_bytes = lpt_sort_bytes(n);
     HIPCHK(r.d_perm.reserve(n));
     HIPCHK(r.sort_ws.reserve(ws_bytes));
-    HIPCHK(r.tickets.reserve(kTicketSlots));
     HIPCHK(r.enc_gs.reserve((size_t)((groups + 3) & ~3) * ENC_GSCRATCH_BYTES));
     // the table, its longest-first order, the encoder: all in stream order, nothing comes back to the host in between
     HIPCHK(launch_series_blocks(d_series_off, d_series_len, n_cont, sel, in_shift, out_cap, d_w_status, d_blocks, d_status, s));
     HIPCHK(launch_lpt_sort(d_blocks, n, r.d_perm.p, r.sort_ws.p, ws_bytes, s));
-    uint32_t* ticket = r.tickets.p + 2 * (r.ticket_next++ % (kTicketSlots / 2));
-    HIPCHK(hipMemsetAsync(ticket, 0, 2 * sizeof(uint32_t), s));
+    uint32_t* ticket = nullptr;
+    if (int trc = next_ticket(r, s, &ticket)) return trc;
     RansArgs a{};
     a.in = d_base;
     a.out = d_out;
@@ -669,6 +696,7 @@ int32_t cramgpu_rans_encode_series_dev(cramgpu_ctx* c, const uint8_t* d_base, in
     a.prof = nullptr;
     a.gscratch = r.enc_gs.p;
     HIPCHK(launch_rans_encode(a, groups, c->enc_lds, s));
+    HIPCHK(hipMemsetAsync(ticket, 0, 2 * sizeof(uint32_t), s));
     return 0;
 }
 

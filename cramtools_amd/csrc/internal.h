@@ -39,9 +39,10 @@ struct RansArgs {
     int32_t n_blocks;
     int32_t* out_len;
     int64_t* out_pos;           // encode only
-    uint32_t* ticket;           // work-queue head, zeroed before the launch (decode: 8 bytes, 8-byte aligned: the
+    uint32_t* ticket;           // work-queue head, zero at the launch (decode: 8 bytes, 8-byte aligned: the
                                 // blocks taken from the front and from the back of perm)
-    uint32_t* simd_arrivals;    // decode: [DEC_SIMD_KEYS] waves of this launch per SIMD, zeroed before the launch; or NULL
+    uint32_t* simd_arrivals;    // decode: [DEC_SIMD_KEYS] number of the last launch whose wave came by, per SIMD; or NULL
+    uint32_t launch_no;         // decode: this launch's number (> every earlier one on this table)
     uint8_t* gscratch;          // n_groups x {ENC,DEC}_GSCRATCH_BYTES
     const uint32_t* rcp_tab;    // [4096] Encoding#RansEncSymbolInit rcp_freq per freq
     int32_t tab_bytes;          // bytes of the LDS table region

@@ -919,18 +919,19 @@ __device__ __forceinline__ void decode_block(const RansArgs& a, int b, uint8_t* 
 // blocks spread over all SIMDs evenly.  One 64-bit counter holds both ends (blocks taken from the front in the low
 // word, from the back in the high word): a ticket is good while their sum is below the number of blocks, so the two
 // ends meet without handing a block out twice, and a wave whose end has run dry simply works from the other side.
-__device__ __forceinline__ bool first_wave_on_simd(uint32_t* arrivals) {
+__device__ __forceinline__ bool first_wave_on_simd(uint32_t* arrivals, uint32_t launch_no) {
 #ifdef HIP_SIM
     (void)arrivals;
+    (void)launch_no;
     return true;
 #else
     if (arrivals == nullptr) return true;
     const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: SIMD 5:4, CU/SH/SE 15:8
     const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
     const uint32_t key = ((xcc & 7u) << 10) | (((hw >> 8) & 255u) << 2) | ((hw >> 4) & 3u);
-    uint32_t rank = 0;
-    if (threadIdx.x == 0) rank = atomicAdd(&arrivals[key], 1u);
-    return __shfl(rank, 0) == 0;
+    uint32_t seen = 0;  // the table keeps the number of the last launch whose wave came by: nothing to clear per launch
+    if (threadIdx.x == 0) seen = atomicMax(&arrivals[key], launch_no);
+    return (uint32_t)__shfl((int)seen, 0) < launch_no;
 #endif
 }
 
@@ -938,7 +939,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(RansArgs a) {
     CRAMGPU_DYN_LDS(smem);
     uint8_t* gs = a.gscratch + (size_t)blockIdx.x * DEC_GSCRATCH_BYTES;
     unsigned long long* ends = reinterpret_cast<unsigned long long*>(a.ticket);
-    const bool front = first_wave_on_simd(a.simd_arrivals);
+    const bool front = first_wave_on_simd(a.simd_arrivals, a.launch_no);
     const uint32_t n = (uint32_t)a.n_blocks;
     for (;;) {
         uint32_t head = 0, tail = 0;

@@ -119,6 +119,14 @@ int32_t cramgpu_rans_encode_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* 
 int32_t cramgpu_rans_encode_static(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* d_blocks,
                                    int32_t n_blocks, int32_t* d_out_len, int64_t* d_out_pos, void* stream);
 
+/* For a caller that launches another kernel BESIDE a rANS launch on a second stream (the gunzip of a batch's GZIP series
+ * beside its rANS decode): makes `stream` wait until the block table of this context's last cramgpu_rans_{encode,decode}_dev
+ * call has reached the device, i.e. until that call's kernel is the next thing in its own stream.  Without it the second
+ * stream's kernel can reach the CUs first when the GPU is backlogged — the rANS kernels are resident grids, and a grid
+ * that finds the wave slots taken starts its long blocks late (decode: 50 ms instead of 26).  No counterpart in the
+ * reference.  Stream-ordered, does not synchronise. */
+int32_t cramgpu_stream_wait_staged(cramgpu_ctx* ctx, void* stream);
+
 /* Device-resident batch decode: block b's raw bytes land at d_out[blocks[b].out_off ..); d_out_len[b] = raw size
  * or a negative code. */
 int32_t cramgpu_rans_decode_dev(cramgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const cramgpu_block* blocks,
