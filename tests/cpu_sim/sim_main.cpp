@@ -187,7 +187,7 @@ static int run_gunzip(cramgpu_ctx* c) {
 static int run_gzip(cramgpu_ctx* c) {
     std::mt19937 rng(17);
     std::vector<Bytes> plain;
-    for (int n : {0, 1, 2, 3, 4, 5, 9, 300, 5000, 32768, 32769, 40000, 70001}) {
+    for (int n : {0, 1, 2, 3, 4, 5, 9, 300, 5000, 32768, 32769, 70001}) {
         Bytes a((size_t)n), b((size_t)n), r((size_t)n), t((size_t)n);
         for (int i = 0; i < n; i++) {
             a[i] = "ACGT"[rng() & 3], b[i] = (uint8_t)((i / 97) % 3 + 60), r[i] = (uint8_t)rng();
@@ -217,6 +217,9 @@ static int run_gzip(cramgpu_ctx* c) {
         for (const Bytes& d : plain) {
             if (bgzf && d.size() > 65000) continue;
             for (int tight = 0; tight < 2; tight++) {
+                // (a slot one byte short: the small inputs and one size behind a block boundary — the thread-per-lane
+                // build under the sanitizers takes a second per large member)
+                if (tight && d.size() > 9000 && d.size() != 32769) continue;
                 Case k;
                 k.in = new Bytes(d);
                 k.in->shrink_to_fit();
