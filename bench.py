@@ -462,7 +462,7 @@ class DecodeStep:
         # G's stream has the lowest priority the device offers: K2 and G become ready at the same moment, and when G's
         # 10 000 workgroups reach the CUs first they keep the decoder's resident waves out for the length of G's streams
         # (K2 50 ms instead of 26: seen in two of eight launches of a profiled run)
-        self.side = torch.cuda.Stream(device=dev, priority=10) if str(dev).startswith("cuda") else None
+        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("BENCH_G_PRIORITY", "10"))) if str(dev).startswith("cuda") else None
 
     def run(self, timed=True):
         w, L, reads = self.w, _lib.lib(), self.w["reads"]
