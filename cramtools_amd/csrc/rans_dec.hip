@@ -4,7 +4,8 @@
 //   RANS#uncompress L29-56, Frequencies#readStats_o0 L13-46, #readStats_o1 L50-106, Decoding L24-90,
 //   D04#uncompress L9-85, D14#uncompress L9-70
 //
-// A resident grid of single-wave workgroups pulling blocks from a ticket counter.  A block is one serial chain (the
+// A resident grid of single-wave workgroups pulling blocks from a two-ended work queue (the first wave of the launch on a
+// SIMD from the front of the longest-first order, later waves from its back: rans_decode_kernel).  A block is one serial chain (the
 // four states share one byte cursor, renormalisation order rans0..rans3 per step), and a lone wave issues about one
 // instruction per 5 cycles whatever it is, so the step is built to be short and to hold ONE LDS round trip:
 //   * each state lives in a 16-lane DPP row (same value in all 16 lanes);
